@@ -1,0 +1,130 @@
+"""ctypes binding of include/canopy.h -- the same stub a maintainer of the reference would add
+(INTEGRATION.md). No torch types cross this boundary: plain pointers and sizes only.
+
+The library is loaded from the in-tree canopy_amd/libcanopy.so. There is no fallback: if the
+HIP extension is missing this raises, and if no GPU is visible canopy_ctx_create returns
+CANOPY_ERR_NO_DEVICE, which `check` turns into CanopyError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcanopy.so")
+
+PARTIAL_DOUBLES = 8
+
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_OUT_OF_MEMORY = -2
+ERR_HIP = -3
+ERR_NO_DEVICE = -4
+ERR_UNSUPPORTED = -5
+ERR_INVALID_MODEL = -6
+ERR_STATE = -7
+
+UPLOAD_VALIDATE = 1
+UPLOAD_DEVICE_POINTERS = 2
+
+APPROX_RARE_EVENT, APPROX_MCUB, APPROX_BOTH = 1, 2, 3
+QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK = 1, 2, 4
+KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS = 0, 1, 2
+
+
+class CtxParams(C.Structure):
+    _fields_ = [("device", C.c_int32), ("n_blocks", C.c_int32), ("stream", C.c_void_p)]
+
+
+class CsrView(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_events", C.c_int32), ("reserved", C.c_int32),
+                ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("row_offset", C.c_int64)]
+
+
+class ModelInfo(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("nnz", C.c_int64), ("row_offset", C.c_int64),
+                ("n_events", C.c_int32), ("max_row_len", C.c_int32),
+                ("device_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64)]
+
+
+class QuantParams(C.Structure):
+    _fields_ = [("approximation", C.c_int32), ("limit_order", C.c_int32), ("cut_off", C.c_double),
+                ("flags", C.c_uint32), ("kernel", C.c_int32)]
+
+
+class Partial(C.Structure):
+    _fields_ = [("rare_hi", C.c_double), ("rare_lo", C.c_double), ("log1p_hi", C.c_double),
+                ("log1p_lo", C.c_double), ("n_kept", C.c_double), ("n_certain", C.c_double),
+                ("max_logp", C.c_double), ("argmax_row", C.c_double)]
+
+
+class QuantResult(C.Structure):
+    _fields_ = [("rare_event", C.c_double), ("mcub", C.c_double), ("n_kept", C.c_int64),
+                ("argmax_row", C.c_int64), ("max_logp", C.c_double), ("elapsed_kernel_ms", C.c_double)]
+
+
+# name -> (restype, argtypes): every symbol include/canopy.h declares
+SIGNATURES = {
+    "canopy_status_string": (C.c_char_p, [C.c_int]),
+    "canopy_version": (None, [C.POINTER(C.c_int)] * 3),
+    "canopy_ctx_create": (C.c_int, [C.POINTER(CtxParams), C.POINTER(C.c_void_p)]),
+    "canopy_ctx_free": (None, [C.c_void_p]),
+    "canopy_last_error": (C.c_char_p, [C.c_void_p]),
+    "canopy_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "canopy_model_upload": (C.c_int, [C.c_void_p, C.POINTER(CsrView), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "canopy_model_synthetic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                         C.POINTER(C.c_void_p)]),
+    "canopy_model_free": (None, [C.c_void_p]),
+    "canopy_model_get_info": (C.c_int, [C.c_void_p, C.POINTER(ModelInfo)]),
+    "canopy_model_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "canopy_model_set_probabilities": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "canopy_quant_params_default": (None, [C.POINTER(QuantParams)]),
+    "canopy_quantify_async": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QuantParams)]),
+    "canopy_quantify_fetch": (C.c_int, [C.c_void_p, C.POINTER(Partial)]),
+    "canopy_quantify": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QuantParams), C.POINTER(QuantResult)]),
+    "canopy_ctx_partials_device": (C.c_void_p, [C.c_void_p]),
+    "canopy_ctx_set_gather_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "canopy_combine_partials": (C.c_int, [C.POINTER(Partial), C.c_int32, C.c_uint32, C.POINTER(QuantResult)]),
+    "canopy_fetch_row_logp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "canopy_fetch_keep_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "canopy_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "canopy_timing_begin": (C.c_int, [C.c_void_p, C.c_int32]),
+    "canopy_timing_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int32)]),
+    "canopy_synthetic_probabilities": (C.c_int, [C.c_uint64, C.c_int32, C.c_void_p]),
+    "canopy_shard_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+}
+
+_lib = None
+
+
+class CanopyError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        msg = "%s failed: %s (%d)" % (where, lib().canopy_status_string(status).decode(), status)
+        if detail:
+            msg += ": " + detail
+        super().__init__(msg)
+
+
+def lib():
+    """Load libcanopy.so (once). Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "canopy_amd/libcanopy.so is missing: build it with `python -m canopy_amd.build` "
+                "(there is no CPU fallback for the quantification path)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status, where, ctx=None):
+    if status != OK:
+        detail = ""
+        if ctx:
+            detail = lib().canopy_last_error(ctx).decode()
+        raise CanopyError(status, where, detail)

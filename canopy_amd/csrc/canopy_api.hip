@@ -1,0 +1,537 @@
+// canopy_api.hip -- the C ABI of include/canopy.h over the gfx950 kernels.
+// Host code only; every entry point catches its own failures and returns a canopy_status
+// (the reference's error style is C++ exceptions, src/mef/openpsa/error.h:23-96, which cannot
+// cross a C boundary). There is deliberately NO CPU fallback anywhere in this file.
+#include <math.h>
+#include <string.h>
+
+#include <new>
+
+#include "canopy_device.h"
+#include "canopy_internal.h"
+
+using namespace canopy;
+
+namespace {
+
+canopy_status fail(canopy_ctx* ctx, canopy_status st, const std::string& msg) {
+    if (ctx) ctx->last_error = msg;
+    return st;
+}
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            (void)hipGetLastError();                                                           \
+            return fail((ctx), _e == hipErrorOutOfMemory ? CANOPY_ERR_OUT_OF_MEMORY : CANOPY_ERR_HIP, \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+        }                                                                                      \
+    } while (0)
+
+struct CSumH {
+    double s = 0.0, c = 0.0;
+    void add(double x) { // Neumaier
+        const double t = s + x;
+        if (fabs(s) >= fabs(x)) c += (s - t) + x; else c += (x - t) + s;
+        s = t;
+    }
+};
+
+canopy_status ensure_block_partials(canopy_ctx* ctx, int grid) {
+    if (grid <= ctx->block_partials_cap) return CANOPY_OK;
+    if (ctx->d_block_partials) (void)hipFree(ctx->d_block_partials);
+    ctx->d_block_partials = nullptr;
+    ctx->block_partials_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_block_partials, sizeof(double) * kAccDoubles * (size_t)grid));
+    ctx->block_partials_cap = grid;
+    return CANOPY_OK;
+}
+
+void free_model_buffers(canopy_model* m) {
+    if (m->d_row_ptr) (void)hipFree(m->d_row_ptr);
+    if (m->d_col_idx) (void)hipFree(m->d_col_idx);
+    if (m->d_logp) (void)hipFree(m->d_logp);
+    m->d_row_ptr = nullptr; m->d_col_idx = nullptr; m->d_logp = nullptr;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* canopy_status_string(canopy_status s) {
+    switch (s) {
+        case CANOPY_OK: return "ok";
+        case CANOPY_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case CANOPY_ERR_OUT_OF_MEMORY: return "out of memory";
+        case CANOPY_ERR_HIP: return "HIP runtime error";
+        case CANOPY_ERR_NO_DEVICE: return "no usable HIP device";
+        case CANOPY_ERR_UNSUPPORTED: return "unsupported";
+        case CANOPY_ERR_INVALID_MODEL: return "invalid CSR model";
+        case CANOPY_ERR_STATE: return "invalid call order";
+    }
+    return "unknown status";
+}
+
+void canopy_version(int* major, int* minor, int* patch) {
+    if (major) *major = CANOPY_VERSION_MAJOR;
+    if (minor) *minor = CANOPY_VERSION_MINOR;
+    if (patch) *patch = CANOPY_VERSION_PATCH;
+}
+
+void canopy_quant_params_default(canopy_quant_params* p) {
+    if (!p) return;
+    p->approximation = CANOPY_APPROX_BOTH;
+    p->limit_order = 20;  // reference settings.h:323
+    p->cut_off = 1e-8;    // reference settings.h:332
+    p->flags = 0;
+    p->kernel = CANOPY_KERNEL_AUTO;
+}
+
+// ---- context -----------------------------------------------------------------------------------
+
+canopy_status canopy_ctx_create(const canopy_ctx_params* params, canopy_ctx** out) {
+    if (!out) return CANOPY_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        (void)hipGetLastError();
+        return CANOPY_ERR_NO_DEVICE; // no CPU path: fail loudly
+    }
+    const int device = params ? params->device : 0;
+    if (device < 0 || device >= n_dev) return CANOPY_ERR_INVALID_ARGUMENT;
+    canopy_ctx* ctx = new (std::nothrow) canopy_ctx();
+    if (!ctx) return CANOPY_ERR_OUT_OF_MEMORY;
+    ctx->device = device;
+    ctx->n_blocks_override = params ? params->n_blocks : 0;
+    canopy_status st = CANOPY_OK;
+    do {
+        hipDeviceProp_t prop;
+        if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+            st = CANOPY_ERR_HIP; break;
+        }
+        ctx->n_cu = prop.multiProcessorCount;
+        ctx->lds_per_block_max = prop.sharedMemPerBlock;
+        if (params && params->stream) {
+            ctx->stream = static_cast<hipStream_t>(params->stream);
+        } else {
+            if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { st = CANOPY_ERR_HIP; break; }
+            ctx->own_stream = true;
+        }
+        if (hipMalloc(&ctx->d_partial, sizeof(double) * CANOPY_PARTIAL_DOUBLES) != hipSuccess ||
+            hipHostMalloc(&ctx->h_partial, sizeof(double) * CANOPY_PARTIAL_DOUBLES) != hipSuccess) {
+            st = CANOPY_ERR_OUT_OF_MEMORY; break;
+        }
+        for (auto& ev : ctx->ev_last)
+            if (hipEventCreate(&ev) != hipSuccess) { st = CANOPY_ERR_HIP; break; }
+    } while (0);
+    if (st != CANOPY_OK) {
+        (void)hipGetLastError();
+        canopy_ctx_free(ctx);
+        return st;
+    }
+    *out = ctx;
+    return CANOPY_OK;
+}
+
+void canopy_ctx_free(canopy_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto ev : ctx->ev_last) if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->d_block_partials) (void)hipFree(ctx->d_block_partials);
+    if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+    if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
+    if (ctx->d_row_logp) (void)hipFree(ctx->d_row_logp);
+    if (ctx->d_keep_mask) (void)hipFree(ctx->d_keep_mask);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* canopy_last_error(const canopy_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+canopy_status canopy_ctx_synchronize(canopy_ctx* ctx) {
+    if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANOPY_OK;
+}
+
+void* canopy_ctx_partials_device(canopy_ctx* ctx) { return ctx ? ctx->d_partial : nullptr; }
+
+canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* device_buffer, int32_t world_size, int32_t rank) {
+    if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (device_buffer && (world_size < 1 || rank < 0 || rank >= world_size))
+        return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "gather buffer: need 0 <= rank < world_size");
+    ctx->d_gather = static_cast<double*>(device_buffer);
+    ctx->gather_world = device_buffer ? world_size : 0;
+    ctx->gather_rank = device_buffer ? rank : 0;
+    return CANOPY_OK;
+}
+
+// ---- model -------------------------------------------------------------------------------------
+
+canopy_status canopy_model_upload(canopy_ctx* ctx, const canopy_csr_view* csr, uint32_t flags,
+                                  canopy_model** out) {
+    if (!ctx || !csr || !out) return CANOPY_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (csr->n_rows < 0 || csr->n_events < 0 || !csr->row_ptr) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "bad csr view");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool dev_ptrs = (flags & CANOPY_UPLOAD_DEVICE_POINTERS) != 0;
+    const hipMemcpyKind kind = dev_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    int64_t ends[2] = {0, 0};
+    if (dev_ptrs) {
+        HIP_TRY(ctx, hipMemcpy(&ends[0], csr->row_ptr, sizeof(int64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(&ends[1], csr->row_ptr + csr->n_rows, sizeof(int64_t), hipMemcpyDeviceToHost));
+    } else {
+        ends[0] = csr->row_ptr[0];
+        ends[1] = csr->row_ptr[csr->n_rows];
+    }
+    const int64_t nnz = ends[1] - ends[0];
+    if (nnz < 0 || (nnz > 0 && !csr->col_idx)) return fail(ctx, CANOPY_ERR_INVALID_MODEL, "row_ptr[R] < row_ptr[0] or col_idx missing");
+
+    canopy_model* m = new (std::nothrow) canopy_model();
+    if (!m) return CANOPY_ERR_OUT_OF_MEMORY;
+    m->device = ctx->device;
+    m->n_rows = csr->n_rows; m->n_events = csr->n_events; m->nnz = nnz; m->row_offset = csr->row_offset;
+    canopy_status st = CANOPY_OK;
+    int64_t* d_status = nullptr;
+    auto cleanup = [&](canopy_status s) {
+        if (d_status) (void)hipFree(d_status);
+        free_model_buffers(m);
+        delete m;
+        return s;
+    };
+#define M_TRY(expr)                                                                             \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            (void)hipGetLastError();                                                            \
+            st = fail(ctx, _e == hipErrorOutOfMemory ? CANOPY_ERR_OUT_OF_MEMORY : CANOPY_ERR_HIP, \
+                      std::string(#expr) + ": " + hipGetErrorString(_e));                       \
+            return cleanup(st);                                                                 \
+        }                                                                                       \
+    } while (0)
+    M_TRY(hipMalloc(&m->d_row_ptr, sizeof(int64_t) * (size_t)(m->n_rows + 1)));
+    M_TRY(hipMalloc(&m->d_col_idx, sizeof(int32_t) * (size_t)nnz + 64));
+    M_TRY(hipMalloc(&m->d_logp, sizeof(double) * (size_t)(m->n_events > 0 ? m->n_events : 1)));
+    M_TRY(hipMemcpyAsync(m->d_row_ptr, csr->row_ptr, sizeof(int64_t) * (size_t)(m->n_rows + 1), kind, ctx->stream));
+    if (nnz > 0) M_TRY(hipMemcpyAsync(m->d_col_idx, csr->col_idx, sizeof(int32_t) * (size_t)nnz, kind, ctx->stream));
+    M_TRY(hipMemsetAsync(reinterpret_cast<char*>(m->d_col_idx) + sizeof(int32_t) * (size_t)nnz, 0, 64, ctx->stream));
+    if (ends[0] != 0) M_TRY(launch_rebase_row_ptr(m->d_row_ptr, m->n_rows + 1, ends[0], ctx->stream));
+    {
+        // validation also yields max_row_len; it always runs (its verdict is only enforced when
+        // the caller asked for it), so a malformed CSR can never index out of bounds later.
+        M_TRY(hipMalloc(&d_status, 2 * sizeof(int64_t)));
+        const int64_t init[2] = {-1 /* = ~0ULL */, 0};
+        M_TRY(hipMemcpyAsync(d_status, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        M_TRY(launch_validate_csr(m->d_row_ptr, m->d_col_idx, m->n_rows, nnz, m->n_events, d_status, ctx->stream));
+        int64_t status[2];
+        M_TRY(hipMemcpyAsync(status, d_status, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+        M_TRY(hipStreamSynchronize(ctx->stream));
+        if (status[0] != -1) {
+            st = fail(ctx, CANOPY_ERR_INVALID_MODEL,
+                      "CSR validation failed at row " + std::to_string(status[0]) +
+                          " (row_ptr not monotone, column out of range, or columns not strictly ascending)");
+            return cleanup(st);
+        }
+        m->max_row_len = (int32_t)status[1];
+        (void)hipFree(d_status);
+        d_status = nullptr;
+    }
+#undef M_TRY
+    (void)flags;
+    m->device_bytes = (int64_t)(sizeof(int64_t) * (size_t)(m->n_rows + 1) + sizeof(int32_t) * (size_t)nnz + 64 +
+                                sizeof(double) * (size_t)m->n_events);
+    *out = m;
+    return CANOPY_OK;
+}
+
+canopy_status canopy_model_synthetic(canopy_ctx* ctx, uint64_t seed, int64_t first_row, int64_t n_rows,
+                                     int32_t n_events, int32_t avg_nnz, canopy_model** out) {
+    if (!ctx || !out) return CANOPY_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (n_rows < 0 || first_row < 0 || avg_nnz < 2 || avg_nnz > 17 || n_events < 2 * avg_nnz - 2)
+        return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "synthetic: need avg_nnz in [2,17], n_events >= 2*avg_nnz-2");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    canopy_model* m = new (std::nothrow) canopy_model();
+    if (!m) return CANOPY_ERR_OUT_OF_MEMORY;
+    m->device = ctx->device;
+    m->n_rows = n_rows; m->n_events = n_events; m->row_offset = first_row;
+    m->max_row_len = 2 * avg_nnz - 2;
+    hipError_t e = synth_build_csr(seed, first_row, n_rows, n_events, avg_nnz, &m->d_row_ptr, &m->d_col_idx,
+                                   &m->nnz, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&m->d_logp, sizeof(double) * (size_t)n_events);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        free_model_buffers(m);
+        delete m;
+        return fail(ctx, e == hipErrorOutOfMemory ? CANOPY_ERR_OUT_OF_MEMORY : CANOPY_ERR_HIP,
+                    std::string("synthetic model: ") + hipGetErrorString(e));
+    }
+    m->device_bytes = (int64_t)(sizeof(int64_t) * (size_t)(n_rows + 1) + sizeof(int32_t) * (size_t)m->nnz + 64 +
+                                sizeof(double) * (size_t)n_events);
+    *out = m;
+    return CANOPY_OK;
+}
+
+void canopy_model_free(canopy_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    free_model_buffers(m);
+    delete m;
+}
+
+canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* info) {
+    if (!m || !info) return CANOPY_ERR_INVALID_ARGUMENT;
+    info->n_rows = m->n_rows; info->nnz = m->nnz; info->row_offset = m->row_offset;
+    info->n_events = m->n_events; info->max_row_len = m->max_row_len;
+    info->device_bytes = m->device_bytes;
+    info->algorithmic_bytes = (m->n_rows + 1) * 8 + m->nnz * 4 + (int64_t)m->n_events * 8;
+    return CANOPY_OK;
+}
+
+canopy_status canopy_model_download(canopy_ctx* ctx, const canopy_model* m, int64_t* row_ptr, int32_t* col_idx) {
+    if (!ctx || !m) return CANOPY_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (row_ptr) HIP_TRY(ctx, hipMemcpyAsync(row_ptr, m->d_row_ptr, sizeof(int64_t) * (size_t)(m->n_rows + 1), hipMemcpyDeviceToHost, ctx->stream));
+    if (col_idx && m->nnz > 0) HIP_TRY(ctx, hipMemcpyAsync(col_idx, m->d_col_idx, sizeof(int32_t) * (size_t)m->nnz, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANOPY_OK;
+}
+
+canopy_status canopy_model_set_probabilities(canopy_ctx* ctx, canopy_model* m, const double* p) {
+    if (!ctx || !m || (!p && m->n_events > 0)) return CANOPY_ERR_INVALID_ARGUMENT;
+    for (int32_t j = 0; j < m->n_events; ++j)
+        if (!(p[j] >= 0.0 && p[j] <= 1.0))
+            return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "probability " + std::to_string(j) + " outside [0,1]");
+    std::vector<double> logp((size_t)m->n_events);
+    for (int32_t j = 0; j < m->n_events; ++j) logp[(size_t)j] = log(p[j]); // glibc log, once, on the host
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (m->n_events > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(m->d_logp, logp.data(), sizeof(double) * (size_t)m->n_events, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // logp is a stack-lifetime buffer
+    m->has_p = true;
+    return CANOPY_OK;
+}
+
+// ---- quantification ----------------------------------------------------------------------------
+
+canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, const canopy_quant_params* params) {
+    if (!ctx || !m) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (m->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "model lives on another device");
+    if (!m->has_p) return fail(ctx, CANOPY_ERR_STATE, "canopy_model_set_probabilities has not been called");
+    canopy_quant_params dflt;
+    if (!params) { canopy_quant_params_default(&dflt); params = &dflt; }
+    if (params->limit_order < 0 || !(params->cut_off >= 0.0))
+        return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "limit_order < 0 or cut_off < 0");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    int variant = params->kernel;
+    if (variant == CANOPY_KERNEL_AUTO)
+        variant = ((size_t)m->n_events <= rows_lds_table_limit_events()) ? CANOPY_KERNEL_ROWS_LDS : CANOPY_KERNEL_ROWS;
+    if (variant != CANOPY_KERNEL_ROWS && variant != CANOPY_KERNEL_ROWS_LDS)
+        return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
+    if (variant == CANOPY_KERNEL_ROWS_LDS && (size_t)m->n_events > rows_lds_table_limit_events())
+        return fail(ctx, CANOPY_ERR_UNSUPPORTED, "logp table does not fit the LDS budget of ROWS_LDS");
+
+    const bool want_rows = (params->flags & CANOPY_QUANT_ROW_LOGP) != 0;
+    const bool want_mask = (params->flags & CANOPY_QUANT_KEEP_MASK) != 0;
+    if (want_rows && ctx->row_logp_cap < m->n_rows) {
+        if (ctx->d_row_logp) (void)hipFree(ctx->d_row_logp);
+        ctx->d_row_logp = nullptr; ctx->row_logp_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_row_logp, sizeof(double) * (size_t)(m->n_rows > 0 ? m->n_rows : 1)));
+        ctx->row_logp_cap = m->n_rows;
+    }
+    const int64_t n_words = (m->n_rows + 63) / 64;
+    if (want_mask && ctx->keep_mask_cap < n_words) {
+        if (ctx->d_keep_mask) (void)hipFree(ctx->d_keep_mask);
+        ctx->d_keep_mask = nullptr; ctx->keep_mask_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_keep_mask, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1)));
+        ctx->keep_mask_cap = n_words;
+    }
+
+    int grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override
+                                          : rows_kernel_default_grid(ctx->n_cu, variant, m->n_rows);
+    canopy_status st = ensure_block_partials(ctx, grid);
+    if (st != CANOPY_OK) return st;
+
+    RowKernelArgs a;
+    a.row_ptr = m->d_row_ptr; a.col_idx = m->d_col_idx; a.logp = m->d_logp;
+    a.n_rows = m->n_rows; a.row_offset = m->row_offset; a.n_events = m->n_events;
+    a.log_cut = params->cut_off > 0.0 ? log(params->cut_off) : -INFINITY; // host glibc log, as the oracle
+    a.limit_order = params->limit_order;
+    a.block_partials = ctx->d_block_partials;
+    a.row_logp_out = want_rows ? ctx->d_row_logp : nullptr;
+    a.keep_mask_out = want_mask ? ctx->d_keep_mask : nullptr;
+
+    hipEvent_t* ev = ctx->ev_last;
+    if (ctx->timing_on && ctx->timing_n < ctx->timing_max) {
+        ev = &ctx->ev_pool[(size_t)ctx->timing_n * 3];
+        ++ctx->timing_n;
+    }
+    HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+    HIP_TRY(ctx, launch_rows_kernel(variant, a, grid, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
+    HIP_TRY(ctx, launch_finalize(ctx->d_block_partials, grid, ctx->d_partial, ctx->d_gather, ctx->gather_world,
+                                 ctx->gather_rank, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
+    if (ev == ctx->ev_last) ctx->last_timed = true;
+    ctx->last_has_row_logp = want_rows;
+    ctx->last_has_mask = want_mask;
+    return CANOPY_OK;
+}
+
+canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* out) {
+    if (!ctx || !out) return CANOPY_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, ctx->d_partial, sizeof(double) * CANOPY_PARTIAL_DOUBLES,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->h_partial, sizeof(canopy_partial));
+    return CANOPY_OK;
+}
+
+canopy_status canopy_combine_partials(const canopy_partial* parts, int32_t n, uint32_t flags, canopy_quant_result* r) {
+    if (!parts || n < 0 || !r) return CANOPY_ERR_INVALID_ARGUMENT;
+    CSumH rare, l1p;
+    double n_kept = 0.0, n_certain = 0.0, max_logp = -INFINITY, argmax = -1.0;
+    for (int32_t k = 0; k < n; ++k) { // index (= rank) order: the same on every rank
+        rare.add(parts[k].rare_hi); rare.add(parts[k].rare_lo);
+        l1p.add(parts[k].log1p_hi); l1p.add(parts[k].log1p_lo);
+        n_kept += parts[k].n_kept; n_certain += parts[k].n_certain;
+        if (parts[k].argmax_row >= 0.0 &&
+            (parts[k].max_logp > max_logp ||
+             (parts[k].max_logp == max_logp && (argmax < 0.0 || parts[k].argmax_row < argmax)))) {
+            max_logp = parts[k].max_logp; argmax = parts[k].argmax_row;
+        }
+    }
+    double rare_v = rare.s + rare.c;
+    if ((flags & CANOPY_QUANT_CLAMP) && rare_v > 1.0) rare_v = 1.0;
+    r->rare_event = rare_v;
+    r->mcub = n_certain > 0.0 ? 1.0 : -expm1(l1p.s + l1p.c);
+    r->n_kept = (int64_t)n_kept;
+    r->argmax_row = (int64_t)argmax;
+    r->max_logp = max_logp;
+    r->elapsed_kernel_ms = -1.0;
+    return CANOPY_OK;
+}
+
+canopy_status canopy_last_kernel_ms(canopy_ctx* ctx, double* row_kernel_ms, double* total_ms) {
+    if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (!ctx->last_timed) return fail(ctx, CANOPY_ERR_STATE, "no timed launch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_last[2]));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev_last[0], ctx->ev_last[1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev_last[0], ctx->ev_last[2]));
+    if (row_kernel_ms) *row_kernel_ms = a;
+    if (total_ms) *total_ms = b;
+    return CANOPY_OK;
+}
+
+canopy_status canopy_quantify(canopy_ctx* ctx, const canopy_model* m, const canopy_quant_params* params,
+                              canopy_quant_result* result) {
+    if (!result) return CANOPY_ERR_INVALID_ARGUMENT;
+    const bool was_timing = ctx ? ctx->timing_on : false;
+    if (ctx) ctx->timing_on = false; // the synchronous call times itself with ev_last
+    canopy_status st = canopy_quantify_async(ctx, m, params);
+    if (ctx) ctx->timing_on = was_timing;
+    if (st != CANOPY_OK) return st;
+    canopy_partial part;
+    st = canopy_quantify_fetch(ctx, &part);
+    if (st != CANOPY_OK) return st;
+    st = canopy_combine_partials(&part, 1, params ? params->flags : 0, result);
+    if (st != CANOPY_OK) return st;
+    double k = -1.0, t = -1.0;
+    if (canopy_last_kernel_ms(ctx, &k, &t) == CANOPY_OK) result->elapsed_kernel_ms = t;
+    return CANOPY_OK;
+}
+
+canopy_status canopy_fetch_row_logp(canopy_ctx* ctx, const canopy_model* m, int64_t first_row, int64_t n, double* out) {
+    if (!ctx || !m || !out || first_row < 0 || n < 0 || first_row + n > m->n_rows) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (!ctx->last_has_row_logp) return fail(ctx, CANOPY_ERR_STATE, "last pass did not request CANOPY_QUANT_ROW_LOGP");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_row_logp + first_row, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANOPY_OK;
+}
+
+canopy_status canopy_fetch_keep_mask(canopy_ctx* ctx, const canopy_model* m, int64_t first_word, int64_t n_words, uint64_t* out) {
+    if (!ctx || !m || !out || first_word < 0 || n_words < 0 || first_word + n_words > (m->n_rows + 63) / 64)
+        return CANOPY_ERR_INVALID_ARGUMENT;
+    if (!ctx->last_has_mask) return fail(ctx, CANOPY_ERR_STATE, "last pass did not request CANOPY_QUANT_KEEP_MASK");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_keep_mask + first_word, sizeof(uint64_t) * (size_t)n_words, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANOPY_OK;
+}
+
+// ---- timing region -----------------------------------------------------------------------------
+
+canopy_status canopy_timing_begin(canopy_ctx* ctx, int32_t max_launches) {
+    if (!ctx || max_launches < 1 || max_launches > (1 << 20)) return CANOPY_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    while ((int)ctx->ev_pool.size() < max_launches * 3) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(ctx, hipEventCreate(&ev));
+        ctx->ev_pool.push_back(ev);
+    }
+    ctx->timing_max = max_launches;
+    ctx->timing_n = 0;
+    ctx->timing_on = true;
+    return CANOPY_OK;
+}
+
+canopy_status canopy_timing_end(canopy_ctx* ctx, double* row_kernel_ms_sum, double* total_ms_sum, int32_t* n_launches) {
+    if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (!ctx->timing_on) return fail(ctx, CANOPY_ERR_STATE, "timing region not open");
+    ctx->timing_on = false;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double ks = 0.0, ts = 0.0;
+    for (int i = 0; i < ctx->timing_n; ++i) {
+        float a = 0.f, b = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev_pool[(size_t)i * 3], ctx->ev_pool[(size_t)i * 3 + 1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev_pool[(size_t)i * 3], ctx->ev_pool[(size_t)i * 3 + 2]));
+        ks += a; ts += b;
+    }
+    if (row_kernel_ms_sum) *row_kernel_ms_sum = ks;
+    if (total_ms_sum) *total_ms_sum = ts;
+    if (n_launches) *n_launches = ctx->timing_n;
+    return CANOPY_OK;
+}
+
+// ---- host logic --------------------------------------------------------------------------------
+
+canopy_status canopy_synthetic_probabilities(uint64_t seed, int32_t n_events, double* p) {
+    if (n_events < 0 || (!p && n_events > 0)) return CANOPY_ERR_INVALID_ARGUMENT;
+    const uint64_t key = stream_key(seed, kStreamProb);
+    for (int32_t j = 0; j < n_events; ++j) {
+        const double u = (double)(draw_keyed(key, (uint64_t)j, 0) >> 11) * 0x1.0p-53;
+        p[j] = pow(10.0, -8.0 + 5.0 * u);
+    }
+    return CANOPY_OK;
+}
+
+canopy_status canopy_shard_rows(const int64_t* row_ptr, int64_t n_rows, int32_t n_shards, int64_t* bounds) {
+    if (!row_ptr || !bounds || n_rows < 0 || n_shards < 1) return CANOPY_ERR_INVALID_ARGUMENT;
+    const int64_t base = row_ptr[0], nnz = row_ptr[n_rows] - base;
+    if (nnz < 0) return CANOPY_ERR_INVALID_MODEL;
+    bounds[0] = 0;
+    for (int32_t k = 1; k < n_shards; ++k) {
+        if (nnz == 0) { bounds[k] = n_rows * k / n_shards; continue; }
+        const int64_t target = base + (int64_t)(((__int128)nnz * k) / n_shards);
+        int64_t lo = 0, hi = n_rows; // first r with row_ptr[r] >= target
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (row_ptr[mid] >= target) hi = mid; else lo = mid + 1;
+        }
+        bounds[k] = lo < bounds[k - 1] ? bounds[k - 1] : lo;
+    }
+    bounds[n_shards] = n_rows;
+    return CANOPY_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,129 @@
+// canopy_device.h -- device-side building blocks shared by the gfx950 kernels.
+// Written for wave64 / CDNA4 only (no other back-end, no compatibility layer).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace canopy {
+
+constexpr int kWave = 64;
+
+// ---- counter-based generator (identical integer arithmetic to oracle/canopy_oracle.c) ----------
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+enum : uint64_t { kStreamLen = 1, kStreamCol = 2, kStreamProb = 3 };
+__host__ __device__ inline uint64_t stream_key(uint64_t seed, uint64_t stream) {
+    return mix64(seed ^ (stream * 0xD1B54A32D192ED03ULL));
+}
+__host__ __device__ inline uint64_t draw_keyed(uint64_t key, uint64_t index, uint64_t t) {
+    return mix64(mix64(key ^ index) + t);
+}
+__host__ __device__ inline uint32_t bounded(uint64_t h, uint32_t n) {
+    return (uint32_t)(((h >> 32) * (uint64_t)n) >> 32);
+}
+
+// ---- compensated accumulation ---------------------------------------------------------------------
+struct CSum {
+    double s, c;
+};
+
+// Neumaier step, branch-free: the error term of a + x is recovered with Knuth's TwoSum, which
+// equals Neumaier's two-branch form whenever no overflow occurs.
+__device__ __forceinline__ void csum_add(CSum& a, double x) {
+    const double t = a.s + x;
+    const double bb = t - a.s;
+    a.c += (a.s - (t - bb)) + (x - bb);
+    a.s = t;
+}
+__device__ __forceinline__ void csum_merge(CSum& a, const CSum& b) {
+    csum_add(a, b.s);
+    a.c += b.c;
+}
+
+__device__ __forceinline__ double shfl_down_f64(double v, int delta) {
+    return __shfl_down(v, delta, kWave);
+}
+
+// One shard-partial in registers.
+struct Acc {
+    CSum rare, l1p;
+    double n_kept, n_certain;
+    double max_logp;
+    double argmax; // global row index as a double (exact < 2^53), -1 = none
+};
+
+__device__ __forceinline__ void acc_init(Acc& a) {
+    a.rare = {0.0, 0.0};
+    a.l1p = {0.0, 0.0};
+    a.n_kept = 0.0;
+    a.n_certain = 0.0;
+    a.max_logp = -__builtin_inf();
+    a.argmax = -1.0;
+}
+
+// a <- a (+) b where every row of a precedes... not assumed: ties resolve to the lower index.
+__device__ __forceinline__ void acc_merge(Acc& a, const Acc& b) {
+    csum_merge(a.rare, b.rare);
+    csum_merge(a.l1p, b.l1p);
+    a.n_kept += b.n_kept;
+    a.n_certain += b.n_certain;
+    const bool take = (b.argmax >= 0.0) &&
+                      ((b.max_logp > a.max_logp) ||
+                       (b.max_logp == a.max_logp && (a.argmax < 0.0 || b.argmax < a.argmax)));
+    a.max_logp = take ? b.max_logp : a.max_logp;
+    a.argmax = take ? b.argmax : a.argmax;
+}
+
+__device__ __forceinline__ Acc acc_shfl_down(const Acc& a, int delta) {
+    Acc r;
+    r.rare.s = shfl_down_f64(a.rare.s, delta);
+    r.rare.c = shfl_down_f64(a.rare.c, delta);
+    r.l1p.s = shfl_down_f64(a.l1p.s, delta);
+    r.l1p.c = shfl_down_f64(a.l1p.c, delta);
+    r.n_kept = shfl_down_f64(a.n_kept, delta);
+    r.n_certain = shfl_down_f64(a.n_certain, delta);
+    r.max_logp = shfl_down_f64(a.max_logp, delta);
+    r.argmax = shfl_down_f64(a.argmax, delta);
+    return r;
+}
+
+// wave64 tree: lane 0 ends with the wave's merged record (fixed order -> reproducible).
+__device__ __forceinline__ void acc_wave_reduce(Acc& a) {
+#pragma unroll
+    for (int d = kWave / 2; d >= 1; d >>= 1) {
+        Acc o = acc_shfl_down(a, d);
+        acc_merge(a, o);
+    }
+}
+
+constexpr int kAccDoubles = 8; // rare.s rare.c l1p.s l1p.c n_kept n_certain max_logp argmax
+
+__device__ __forceinline__ void acc_store(double* dst, const Acc& a) {
+    dst[0] = a.rare.s; dst[1] = a.rare.c; dst[2] = a.l1p.s; dst[3] = a.l1p.c;
+    dst[4] = a.n_kept; dst[5] = a.n_certain; dst[6] = a.max_logp; dst[7] = a.argmax;
+}
+__device__ __forceinline__ void acc_load(Acc& a, const double* src) {
+    a.rare.s = src[0]; a.rare.c = src[1]; a.l1p.s = src[2]; a.l1p.c = src[3];
+    a.n_kept = src[4]; a.n_certain = src[5]; a.max_logp = src[6]; a.argmax = src[7];
+}
+
+// Per-row epilogue shared by every row kernel: filter, P = exp(s), both sums, argmax.
+__device__ __forceinline__ bool row_epilogue(Acc& a, double s, int len, bool valid, double log_cut,
+                                            int limit_order, double global_row) {
+    const bool keep = valid && (s >= log_cut) && (limit_order == 0 || len <= limit_order);
+    if (keep) {
+        const double P = exp(s);
+        csum_add(a.rare, P);
+        if (P < 1.0) csum_add(a.l1p, log1p(-P)); else a.n_certain += 1.0;
+        a.n_kept += 1.0;
+        if (s > a.max_logp) { a.max_logp = s; a.argmax = global_row; }
+    }
+    return keep;
+}
+
+} // namespace canopy

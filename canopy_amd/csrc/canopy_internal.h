@@ -1,0 +1,86 @@
+// canopy_internal.h -- host-side state behind the opaque handles of include/canopy.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "canopy.h"
+
+struct canopy_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 0;
+    int n_blocks_override = 0;
+    size_t lds_per_block_max = 0;
+
+    double* d_block_partials = nullptr; // [block_partials_cap][8]
+    int block_partials_cap = 0;
+    double* d_partial = nullptr;        // the shard record, 8 doubles
+    double* h_partial = nullptr;        // pinned mirror
+    double* d_gather = nullptr;         // caller-owned all-reduce buffer [world][8], optional
+    int gather_world = 0, gather_rank = 0;
+
+    double* d_row_logp = nullptr;       // optional outputs of the last pass
+    int64_t row_logp_cap = 0;
+    uint64_t* d_keep_mask = nullptr;
+    int64_t keep_mask_cap = 0;
+    bool last_has_row_logp = false, last_has_mask = false;
+
+    hipEvent_t ev_last[3] = {nullptr, nullptr, nullptr};
+    bool last_timed = false;
+    // timing region
+    std::vector<hipEvent_t> ev_pool; // 3 per launch
+    int timing_max = 0, timing_n = 0;
+    bool timing_on = false;
+
+    std::string last_error;
+};
+
+struct canopy_model {
+    int device = 0;
+    int64_t n_rows = 0, nnz = 0, row_offset = 0;
+    int32_t n_events = 0, max_row_len = 0;
+    int64_t* d_row_ptr = nullptr; // [n_rows+1], rebased to 0
+    int32_t* d_col_idx = nullptr; // [nnz] (+ 16 B of slack for 16-byte slab loads)
+    double* d_logp = nullptr;     // [n_events]
+    bool has_p = false;
+    int64_t device_bytes = 0;
+};
+
+namespace canopy {
+
+struct RowKernelArgs {
+    const int64_t* row_ptr;
+    const int32_t* col_idx;
+    const double* logp;
+    int64_t n_rows;
+    int64_t row_offset;
+    int32_t n_events;
+    double log_cut;
+    int32_t limit_order;
+    double* block_partials; // [grid][8]
+    double* row_logp_out;   // nullable
+    uint64_t* keep_mask_out;// nullable
+};
+
+// kernels_rows.hip
+int rows_kernel_default_grid(int n_cu, int variant, int64_t n_rows);
+size_t rows_lds_table_limit_events();
+hipError_t launch_rows_kernel(int variant, const RowKernelArgs& a, int grid, hipStream_t s);
+hipError_t launch_finalize(const double* block_partials, int n_blocks, double* out, double* gather,
+                           int world, int rank, hipStream_t s);
+
+// kernels_build.hip
+hipError_t launch_validate_csr(const int64_t* row_ptr, const int32_t* col_idx, int64_t n_rows,
+                               int64_t nnz, int32_t n_events, int64_t* d_status /*[2]: first bad row, max len*/,
+                               hipStream_t s);
+hipError_t launch_rebase_row_ptr(int64_t* row_ptr, int64_t n_plus_1, int64_t base, hipStream_t s);
+hipError_t synth_build_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int32_t n_events,
+                           int32_t avg_nnz, int64_t** d_row_ptr_out, int32_t** d_col_idx_out,
+                           int64_t* nnz_out, hipStream_t s);
+
+} // namespace canopy

@@ -1,0 +1,61 @@
+"""K5 -- cross-GPU combine of the shard partials: ONE sum all-reduce (RCCL over xGMI).
+
+Cut-set rows partition trivially across ranks (one process per GPU); the only exchange step of
+the path is the combine of the per-shard partial records. Each rank's final-reduce kernel writes
+its record into slot `rank` of a world_size x 8 buffer and zeroes the other slots
+(canopy_ctx_set_gather_buffer), so a single `all_reduce(SUM)` is an all-gather of the records:
+every rank then folds them in rank order with canopy_combine_partials -> bitwise identical results
+on all ranks, independent of RCCL's reduction order (x + 0 is exact). The message is
+world_size * 64 B: latency-bound, xGMI link bandwidth is irrelevant.
+
+The same class runs on CPU tensors with the gloo backend (tests/test_distributed.py), where the
+local record is put into the slot by the host instead of the kernel.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _capi as capi
+from .quantifier import combine_partials
+
+
+class ShardCombiner:
+    def __init__(self, ctx=None, group=None, device=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.ctx = ctx
+        if ctx is not None:
+            device = torch.device("cuda", ctx.device) if device is None else device
+        else:
+            device = torch.device("cpu") if device is None else device
+        self.buf = torch.zeros(self.world * capi.PARTIAL_DOUBLES, dtype=torch.float64, device=device)
+        if ctx is not None:
+            capi.check(capi.lib().canopy_ctx_set_gather_buffer(ctx.handle, self.buf.data_ptr(), self.world,
+                                                               self.rank), "canopy_ctx_set_gather_buffer", ctx.handle)
+
+    def detach(self):
+        if self.ctx is not None:
+            capi.lib().canopy_ctx_set_gather_buffer(self.ctx.handle, None, 0, 0)
+
+    def put_local(self, partial):
+        """CPU / test path: place this rank's record (capi.Partial) in its slot, zero the others."""
+        rec = np.frombuffer(bytes(partial), dtype=np.float64).copy()
+        self.buf.zero_()
+        n = capi.PARTIAL_DOUBLES
+        self.buf[self.rank * n:(self.rank + 1) * n] = torch.from_numpy(rec).to(self.buf.device)
+
+    def all_reduce(self):
+        """The single collective of the path. Enqueued on the current stream for RCCL."""
+        if self.world > 1:
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+
+    def partials(self):
+        host = self.buf.detach().to("cpu").numpy()
+        n = capi.PARTIAL_DOUBLES
+        return [capi.Partial(*host[k * n:(k + 1) * n].tolist()) for k in range(self.world)]
+
+    def result(self, flags=0):
+        return combine_partials(self.partials(), flags)

@@ -1,0 +1,209 @@
+"""Host-side mirror of the C ABI (include/canopy.h) for the cut-set quantification path.
+
+Thin RAII objects over the opaque handles -- the Python analogue of include/canopy-cpp.h, which
+follows the reference's unique_ptr-wrapper header shape (reference include/canopy-cpp.h:34-40).
+Names, argument meaning and defaults are the ABI's, which in turn mirror
+mef::openpsa::Settings (reference src/mef/openpsa/settings.h:19,314-332).
+
+Everything here goes through libcanopy.so; nothing falls back to numpy or to oracle/.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi as capi
+
+
+@dataclass
+class QuantResult:
+    rare_event: float
+    mcub: float
+    n_kept: int
+    argmax_row: int
+    max_logp: float
+    elapsed_kernel_ms: float = -1.0
+
+
+def _as(arr, dtype):
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    return a
+
+
+class Context:
+    """One device, one stream (canopy_ctx). `stream` is a raw hipStream_t integer or None."""
+
+    def __init__(self, device=0, stream=None, n_blocks=0):
+        self._h = C.c_void_p()
+        p = capi.CtxParams(device=device, n_blocks=n_blocks, stream=stream)
+        capi.check(capi.lib().canopy_ctx_create(C.byref(p), C.byref(self._h)), "canopy_ctx_create")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            capi.lib().canopy_ctx_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def synchronize(self):
+        capi.check(capi.lib().canopy_ctx_synchronize(self._h), "canopy_ctx_synchronize", self._h)
+
+    def partials_device_ptr(self):
+        return capi.lib().canopy_ctx_partials_device(self._h)
+
+    # -- models ---------------------------------------------------------------------------------
+    def upload(self, row_ptr, col_idx, n_events, row_offset=0, validate=True):
+        row_ptr = _as(row_ptr, np.int64)
+        col_idx = _as(col_idx, np.int32)
+        view = capi.CsrView(n_rows=len(row_ptr) - 1, n_events=n_events, reserved=0,
+                            row_ptr=row_ptr.ctypes.data, col_idx=col_idx.ctypes.data if col_idx.size else None,
+                            row_offset=row_offset)
+        h = C.c_void_p()
+        capi.check(capi.lib().canopy_model_upload(self._h, C.byref(view), capi.UPLOAD_VALIDATE if validate else 0,
+                                                  C.byref(h)), "canopy_model_upload", self._h)
+        return Model(self, h)
+
+    def synthetic(self, seed, n_rows, n_events, avg_nnz, first_row=0):
+        h = C.c_void_p()
+        capi.check(capi.lib().canopy_model_synthetic(self._h, seed, first_row, n_rows, n_events, avg_nnz,
+                                                     C.byref(h)), "canopy_model_synthetic", self._h)
+        return Model(self, h)
+
+    # -- quantification ---------------------------------------------------------------------------
+    def quantify_async(self, model, params=None):
+        capi.check(capi.lib().canopy_quantify_async(self._h, model.handle, C.byref(params) if params else None),
+                   "canopy_quantify_async", self._h)
+
+    def fetch_partial(self):
+        part = capi.Partial()
+        capi.check(capi.lib().canopy_quantify_fetch(self._h, C.byref(part)), "canopy_quantify_fetch", self._h)
+        return part
+
+    def quantify(self, model, params=None):
+        res = capi.QuantResult()
+        capi.check(capi.lib().canopy_quantify(self._h, model.handle, C.byref(params) if params else None,
+                                              C.byref(res)), "canopy_quantify", self._h)
+        return QuantResult(res.rare_event, res.mcub, res.n_kept, res.argmax_row, res.max_logp,
+                           res.elapsed_kernel_ms)
+
+    def last_kernel_ms(self):
+        a, b = C.c_double(), C.c_double()
+        capi.check(capi.lib().canopy_last_kernel_ms(self._h, C.byref(a), C.byref(b)), "canopy_last_kernel_ms", self._h)
+        return a.value, b.value
+
+    def timing_begin(self, max_launches):
+        capi.check(capi.lib().canopy_timing_begin(self._h, max_launches), "canopy_timing_begin", self._h)
+
+    def timing_end(self):
+        a, b, n = C.c_double(), C.c_double(), C.c_int32()
+        capi.check(capi.lib().canopy_timing_end(self._h, C.byref(a), C.byref(b), C.byref(n)), "canopy_timing_end", self._h)
+        return a.value, b.value, n.value
+
+    def fetch_row_logp(self, model, first_row=0, n=None):
+        n = model.info().n_rows - first_row if n is None else n
+        out = np.empty(n, dtype=np.float64)
+        capi.check(capi.lib().canopy_fetch_row_logp(self._h, model.handle, first_row, n, out.ctypes.data),
+                   "canopy_fetch_row_logp", self._h)
+        return out
+
+    def fetch_keep_mask(self, model, first_word=0, n_words=None):
+        total = (model.info().n_rows + 63) // 64
+        n_words = total - first_word if n_words is None else n_words
+        out = np.empty(n_words, dtype=np.uint64)
+        capi.check(capi.lib().canopy_fetch_keep_mask(self._h, model.handle, first_word, n_words, out.ctypes.data),
+                   "canopy_fetch_keep_mask", self._h)
+        return out
+
+
+class Model:
+    """A CSR cut-set shard resident in HBM (canopy_model)."""
+
+    def __init__(self, ctx, handle):
+        self._ctx = ctx
+        self._h = handle
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            capi.lib().canopy_model_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        info = capi.ModelInfo()
+        capi.check(capi.lib().canopy_model_get_info(self._h, C.byref(info)), "canopy_model_get_info")
+        return info
+
+    def download(self):
+        info = self.info()
+        row_ptr = np.empty(info.n_rows + 1, dtype=np.int64)
+        col_idx = np.empty(info.nnz, dtype=np.int32)
+        capi.check(capi.lib().canopy_model_download(self._ctx.handle, self._h, row_ptr.ctypes.data,
+                                                    col_idx.ctypes.data if info.nnz else None),
+                   "canopy_model_download", self._ctx.handle)
+        return row_ptr, col_idx
+
+    def set_probabilities(self, p):
+        p = _as(p, np.float64)
+        if p.shape != (self.info().n_events,):
+            raise ValueError("p must have n_events entries")
+        capi.check(capi.lib().canopy_model_set_probabilities(self._ctx.handle, self._h, p.ctypes.data),
+                   "canopy_model_set_probabilities", self._ctx.handle)
+
+
+def default_params(cut_off=None, limit_order=None, flags=0, kernel=capi.KERNEL_AUTO):
+    p = capi.QuantParams()
+    capi.lib().canopy_quant_params_default(C.byref(p))
+    if cut_off is not None:
+        p.cut_off = cut_off
+    if limit_order is not None:
+        p.limit_order = limit_order
+    p.flags = flags
+    p.kernel = kernel
+    return p
+
+
+def synthetic_probabilities(seed, n_events):
+    p = np.empty(n_events, dtype=np.float64)
+    capi.check(capi.lib().canopy_synthetic_probabilities(seed, n_events, p.ctypes.data),
+               "canopy_synthetic_probabilities")
+    return p
+
+
+def shard_rows(row_ptr, n_shards):
+    row_ptr = _as(row_ptr, np.int64)
+    bounds = np.empty(n_shards + 1, dtype=np.int64)
+    capi.check(capi.lib().canopy_shard_rows(row_ptr.ctypes.data, len(row_ptr) - 1, n_shards, bounds.ctypes.data),
+               "canopy_shard_rows")
+    return bounds
+
+
+def combine_partials(parts, flags=0):
+    """parts: sequence of capi.Partial (rank order) -> QuantResult (canopy_combine_partials)."""
+    arr = (capi.Partial * len(parts))(*parts)
+    res = capi.QuantResult()
+    capi.check(capi.lib().canopy_combine_partials(arr, len(parts), flags, C.byref(res)), "canopy_combine_partials")
+    return QuantResult(res.rare_event, res.mcub, res.n_kept, res.argmax_row, res.max_logp, -1.0)

@@ -1,0 +1,280 @@
+/*
+ * canopy.h -- C ABI of the MI355X-native cut-set quantification path.
+ *
+ * The reference ships this header as an empty include guard
+ * (reference include/canopy.h:33-36) and src/canopy.cpp as a licence comment
+ * (reference src/canopy.cpp:1-31): the quantifier is the hole this library fills.
+ * Conventions kept from the reference scaffold:
+ *   - plain C header, no C++ in the signatures (cmake/canopy-config.cmake.in:25
+ *     promises C consumers; int64_t needs <stdint.h>, so C99 is the floor),
+ *   - CANOPY_SHARED / CANOPY_BUILD visibility defines (reference src/CMakeLists.txt:19-23),
+ *   - a separate C++-only RAII header (reference include/canopy-cpp.h:34-40).
+ * Parameter names and defaults mirror mef::openpsa::Settings
+ * (reference src/mef/openpsa/settings.h:19,22,314-332): approximation
+ * {rare-event, mcub, monte-carlo}, cut_off 1e-8, limit_order 20, num_trials 1e3, seed 0.
+ *
+ * Semantics (the canonical arithmetic; oracle/canopy_oracle.c is its CPU restatement):
+ *   rows    = minimal cut sets, columns = basic events, CSR, columns ascending per row
+ *   logp[j] = log(p[j])                      computed once on the host (glibc log)
+ *   s_i     = ((logp[c0] + logp[c1]) + ...)  plain fp64 adds in CSR order
+ *   keep_i  = s_i >= log(cut_off)  &&  (limit_order == 0 || len_i <= limit_order)
+ *   P_i     = exp(s_i)
+ *   rare    = sum_{keep} P_i                 (compensated)
+ *   mcub    = 1 - prod_{keep} (1 - P_i) = -expm1( sum_{keep} log1p(-P_i) )
+ *   n_kept, argmax_i s_i (ties -> lowest i), optional keep bitmask and per-row s_i
+ * Integer outputs are bit-exact against the oracle; rare/mcub agree to <= 1e-12 relative.
+ *
+ * Every entry point returns canopy_status; no exception crosses this boundary.
+ * A canopy_ctx is bound to ONE device (one process per GPU); it is not thread-safe.
+ * The library never falls back to a CPU path: without a usable HIP device
+ * canopy_ctx_create fails with CANOPY_ERR_NO_DEVICE.
+ */
+#ifndef CANOPY_CANOPY_H
+#define CANOPY_CANOPY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(CANOPY_SHARED) && defined(_WIN32)
+#  ifdef CANOPY_BUILD
+#    define CANOPY_API __declspec(dllexport)
+#  else
+#    define CANOPY_API __declspec(dllimport)
+#  endif
+#elif defined(__GNUC__)
+#  define CANOPY_API __attribute__((visibility("default")))
+#else
+#  define CANOPY_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CANOPY_VERSION_MAJOR 0
+#define CANOPY_VERSION_MINOR 1
+#define CANOPY_VERSION_PATCH 0
+
+/* ---- status ------------------------------------------------------------------------------- */
+typedef enum canopy_status {
+    CANOPY_OK = 0,
+    CANOPY_ERR_INVALID_ARGUMENT = -1,
+    CANOPY_ERR_OUT_OF_MEMORY = -2,
+    CANOPY_ERR_HIP = -3,
+    CANOPY_ERR_NO_DEVICE = -4,
+    CANOPY_ERR_UNSUPPORTED = -5,
+    CANOPY_ERR_INVALID_MODEL = -6, /* CSR failed validation (row_ptr not monotone, column out of
+                                      range, columns not strictly ascending within a row) */
+    CANOPY_ERR_STATE = -7          /* call order violated (e.g. quantify before set_probabilities) */
+} canopy_status;
+
+CANOPY_API const char* canopy_status_string(canopy_status s);
+CANOPY_API void canopy_version(int* major, int* minor, int* patch);
+
+/* ---- context ------------------------------------------------------------------------------ */
+typedef struct canopy_ctx canopy_ctx;
+
+typedef struct canopy_ctx_params {
+    int32_t device;  /* HIP device ordinal; the process-per-GPU launcher passes LOCAL_RANK */
+    int32_t n_blocks;/* persistent grid size override, 0 = library default for the device */
+    void* stream;    /* hipStream_t to launch on, NULL = the library creates its own */
+} canopy_ctx_params;
+
+CANOPY_API canopy_status canopy_ctx_create(const canopy_ctx_params* params, canopy_ctx** out);
+CANOPY_API void canopy_ctx_free(canopy_ctx* ctx);
+/* Last HIP / validation error text captured by this context ("" if none). Owned by the ctx. */
+CANOPY_API const char* canopy_last_error(const canopy_ctx* ctx);
+/* Block the host until everything enqueued on the context's stream has finished. */
+CANOPY_API canopy_status canopy_ctx_synchronize(canopy_ctx* ctx);
+
+/* ---- model: the CSR cut-set x basic-event incidence matrix, resident in HBM ----------------- */
+typedef struct canopy_model canopy_model;
+
+typedef struct canopy_csr_view {
+    int64_t n_rows;         /* R: cut sets held by THIS shard */
+    int32_t n_events;       /* E: basic events (columns) */
+    int32_t reserved;
+    const int64_t* row_ptr; /* [R+1], row_ptr[0] may be non-zero (a slice of a larger array) */
+    const int32_t* col_idx; /* [row_ptr[R]-row_ptr[0]] when sliced: entry k of the view is
+                               col_idx[k - row_ptr[0]] ... see canopy_model_upload */
+    int64_t row_offset;     /* global index of this shard's row 0 (argmax is reported globally) */
+} canopy_csr_view;
+
+enum {
+    CANOPY_UPLOAD_VALIDATE = 1u,      /* run the CSR validation kernel (default for host callers) */
+    CANOPY_UPLOAD_DEVICE_POINTERS = 2u /* row_ptr/col_idx already live in device memory; they are
+                                          copied device-to-device (the library owns its copy) */
+};
+
+/*
+ * Copies the CSR to the device. row_ptr is rebased so that the stored row_ptr[0] == 0;
+ * col_idx must point at the entry that row_ptr[0] designates (i.e. the slice's first entry).
+ * The caller keeps ownership of the host arrays and may free them when this returns.
+ */
+CANOPY_API canopy_status canopy_model_upload(canopy_ctx* ctx, const canopy_csr_view* csr,
+                                             uint32_t flags, canopy_model** out);
+
+/*
+ * Generates, directly in HBM, rows [first_row, first_row + n_rows) of the deterministic
+ * synthetic CSR family of the benchmark driver (replaces the reference's empty benchmarks/,
+ * reference benchmarks/CMakeLists.txt): row length uniform on {2 .. 2*avg_nnz-2},
+ * len distinct uniform columns per row, ascending. Counter-based (splitmix64), so any
+ * row range of the same (seed, n_events, avg_nnz) family is identical wherever it is made;
+ * oracle/canopy_oracle.c holds the CPU restatement. row_offset of the model = first_row.
+ */
+CANOPY_API canopy_status canopy_model_synthetic(canopy_ctx* ctx, uint64_t seed, int64_t first_row,
+                                                int64_t n_rows, int32_t n_events, int32_t avg_nnz,
+                                                canopy_model** out);
+
+CANOPY_API void canopy_model_free(canopy_model* model);
+
+typedef struct canopy_model_info {
+    int64_t n_rows;
+    int64_t nnz;
+    int64_t row_offset;
+    int32_t n_events;
+    int32_t max_row_len;
+    int64_t device_bytes;       /* bytes of HBM the model holds */
+    int64_t algorithmic_bytes;  /* (R+1)*8 + nnz*4 + E*8: compulsory traffic of one sum-only pass */
+} canopy_model_info;
+
+CANOPY_API canopy_status canopy_model_get_info(const canopy_model* model, canopy_model_info* info);
+
+/* Copy the device CSR back (row_ptr rebased to 0). Either pointer may be NULL. */
+CANOPY_API canopy_status canopy_model_download(canopy_ctx* ctx, const canopy_model* model,
+                                               int64_t* row_ptr, int32_t* col_idx);
+
+/*
+ * Basic-event probabilities (reference BasicEvent::p(), src/mef/openpsa/event/event.h:93-96),
+ * p[E] on the host, each in [0,1]. logp = log(p) is evaluated here, on the host, once
+ * (canonical semantics above) and uploaded; quantify calls then run with inputs resident.
+ */
+CANOPY_API canopy_status canopy_model_set_probabilities(canopy_ctx* ctx, canopy_model* model,
+                                                        const double* p);
+
+/* ---- quantification ------------------------------------------------------------------------ */
+typedef enum canopy_approximation { /* reference settings.h:19 Approximation */
+    CANOPY_APPROX_RARE_EVENT = 1,
+    CANOPY_APPROX_MCUB = 2,
+    CANOPY_APPROX_BOTH = 3
+} canopy_approximation;
+
+enum {
+    CANOPY_QUANT_CLAMP = 1u,       /* rare_event = min(1, sum) */
+    CANOPY_QUANT_ROW_LOGP = 2u,    /* also write s_i for every row (R*8 B of extra HBM stores) */
+    CANOPY_QUANT_KEEP_MASK = 4u    /* also write the survivor bitmask, bit (i%64) of word i/64 */
+};
+
+typedef struct canopy_quant_params {
+    int32_t approximation; /* canopy_approximation; both sums are always accumulated */
+    int32_t limit_order;   /* reference settings.h:323 default 20; 0 disables */
+    double cut_off;        /* reference settings.h:332 default 1e-8; 0 disables */
+    uint32_t flags;
+    int32_t kernel;        /* 0 = auto; otherwise force a CANOPY_KERNEL_* variant */
+} canopy_quant_params;
+
+enum {
+    CANOPY_KERNEL_AUTO = 0,
+    CANOPY_KERNEL_ROWS = 1,     /* lane-per-row, LDS-staged col_idx slab, logp gathered via L2 */
+    CANOPY_KERNEL_ROWS_LDS = 2  /* same, logp table resident in LDS (needs E*8 B <= table budget) */
+};
+
+CANOPY_API void canopy_quant_params_default(canopy_quant_params* params);
+
+/*
+ * One shard's partial result. Fixed layout of CANOPY_PARTIAL_DOUBLES doubles so that the
+ * cross-GPU combine is a single sum all-reduce of world_size records (each rank fills only
+ * its own slot), then canopy_combine_partials in rank order: deterministic on every rank.
+ */
+#define CANOPY_PARTIAL_DOUBLES 8
+typedef struct canopy_partial {
+    double rare_hi;     /* compensated sum of P_i over kept rows: value = hi + lo */
+    double rare_lo;
+    double log1p_hi;    /* compensated sum of log1p(-P_i) over kept rows with P_i < 1 */
+    double log1p_lo;
+    double n_kept;      /* exact integer < 2^53 */
+    double n_certain;   /* kept rows with P_i >= 1 (mcub = 1 if any) */
+    double max_logp;    /* max s_i over kept rows, -inf if none */
+    double argmax_row;  /* global row index of that max (lowest on ties), -1 if none */
+} canopy_partial;
+
+typedef struct canopy_quant_result {
+    double rare_event;
+    double mcub;
+    int64_t n_kept;
+    int64_t argmax_row;
+    double max_logp;
+    double elapsed_kernel_ms; /* device time of the last pass (HIP events), -1 if not timed */
+} canopy_quant_result;
+
+/*
+ * Enqueue one quantification pass over the model on the context's stream: the row kernel
+ * plus the deterministic final reduce. Returns without waiting. The partial record lands in
+ * the context's device buffer (canopy_ctx_partials_device).
+ */
+CANOPY_API canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* model,
+                                               const canopy_quant_params* params);
+/* Wait for the stream, copy the partial record to the host. */
+CANOPY_API canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* out);
+/* Synchronous convenience: async + fetch + combine of the single shard; fills elapsed_kernel_ms. */
+CANOPY_API canopy_status canopy_quantify(canopy_ctx* ctx, const canopy_model* model,
+                                         const canopy_quant_params* params,
+                                         canopy_quant_result* result);
+
+/* Device address of the context's canopy_partial record (CANOPY_PARTIAL_DOUBLES doubles). */
+CANOPY_API void* canopy_ctx_partials_device(canopy_ctx* ctx);
+
+/*
+ * Multi-GPU (one process per GPU): point the context at a device buffer of
+ * world_size * CANOPY_PARTIAL_DOUBLES doubles. Every later pass also writes this rank's record
+ * into slot `rank` and zeroes the other slots in its final-reduce kernel, so that ONE
+ * sum all-reduce (RCCL over xGMI) of the buffer delivers every rank's record to every rank --
+ * no other collective, no host round trip. Pass NULL to detach.
+ */
+CANOPY_API canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* device_buffer,
+                                                      int32_t world_size, int32_t rank);
+
+/* Host-side, deterministic combine of n shard records in index order. */
+CANOPY_API canopy_status canopy_combine_partials(const canopy_partial* parts, int32_t n,
+                                                 uint32_t flags, canopy_quant_result* result);
+
+/* Optional per-row outputs of the last pass that requested them (host destination). */
+CANOPY_API canopy_status canopy_fetch_row_logp(canopy_ctx* ctx, const canopy_model* model,
+                                               int64_t first_row, int64_t n, double* out);
+CANOPY_API canopy_status canopy_fetch_keep_mask(canopy_ctx* ctx, const canopy_model* model,
+                                                int64_t first_word, int64_t n_words, uint64_t* out);
+
+/*
+ * Device time of the last `canopy_quantify_async` row kernel alone, measured with HIP events
+ * on the context's stream (blocks until it has finished). Used by the benchmark's roofline.
+ */
+CANOPY_API canopy_status canopy_last_kernel_ms(canopy_ctx* ctx, double* row_kernel_ms,
+                                               double* total_ms);
+
+/* ---- per-launch timing over a region (HIP events on the context's stream) -------------------- */
+/*
+ * Between begin and end every canopy_quantify_async records an event triple around its row
+ * kernel and its final reduce (up to max_launches launches; later ones are not timed).
+ * end synchronises the stream and returns the summed device times and the launch count.
+ */
+CANOPY_API canopy_status canopy_timing_begin(canopy_ctx* ctx, int32_t max_launches);
+CANOPY_API canopy_status canopy_timing_end(canopy_ctx* ctx, double* row_kernel_ms_sum,
+                                           double* total_ms_sum, int32_t* n_launches);
+
+/* ---- synthetic inputs (host logic) ----------------------------------------------------------- */
+/* p_j = 10^(-8 + 5 u_j), u_j uniform [0,1) from the same counter-based generator: p[n_events]. */
+CANOPY_API canopy_status canopy_synthetic_probabilities(uint64_t seed, int32_t n_events, double* p);
+
+/* ---- sharding (host logic, no device needed) ------------------------------------------------ */
+/*
+ * Contiguous row ranges balanced by nnz: bounds[n_shards+1], bounds[0] = 0,
+ * bounds[n_shards] = n_rows; shard k owns rows [bounds[k], bounds[k+1]).
+ */
+CANOPY_API canopy_status canopy_shard_rows(const int64_t* row_ptr, int64_t n_rows, int32_t n_shards,
+                                           int64_t* bounds);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CANOPY_CANOPY_H */

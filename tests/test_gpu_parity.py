@@ -1,0 +1,222 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+Bar: integer/index outputs and per-row s_i bit-exact; rare-event / MCUB <= 1e-12 relative."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20250704
+TOL = 1e-12  # north_star: top-event probability within 1e-12 relative of the CPU reference
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quantify_mpmath.json")
+
+
+def csr(rows):
+    row_ptr = np.zeros(len(rows) + 1, dtype=np.int64)
+    for i, r in enumerate(rows):
+        row_ptr[i + 1] = row_ptr[i] + len(r)
+    return row_ptr, np.array([c for r in rows for c in r], dtype=np.int32)
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def variants(n_events):
+    from canopy_amd import _capi
+    v = [_capi.KERNEL_ROWS]
+    if n_events <= 12288:
+        v.append(_capi.KERNEL_ROWS_LDS)
+    return v
+
+
+def check_against_oracle(ctx, oracle, row_ptr, col, p, n_events, cut_off, limit_order, row_offset=0, threads=4):
+    from canopy_amd import _capi, default_params
+    want = oracle.quantify(row_ptr, col, p, cut_off=cut_off, limit_order=limit_order, n_threads=threads,
+                           row_offset=row_offset)
+    model = ctx.upload(row_ptr, col, n_events, row_offset=row_offset)
+    model.set_probabilities(p)
+    for kern in variants(n_events):
+        prm = default_params(cut_off=cut_off, limit_order=limit_order,
+                             flags=_capi.QUANT_ROW_LOGP | _capi.QUANT_KEEP_MASK, kernel=kern)
+        got = ctx.quantify(model, prm)
+        assert got.n_kept == int(want.n_kept), kern
+        assert got.argmax_row == int(want.argmax_row), kern
+        if want.n_kept:
+            assert got.max_logp == want.max_logp, kern
+        if len(row_ptr) > 1:
+            assert np.array_equal(ctx.fetch_row_logp(model), want.row_logp), kern  # bit-exact s_i
+            assert np.array_equal(ctx.fetch_keep_mask(model), want.keep_mask), kern
+        if math.isfinite(want.rare_event) and want.rare_event > 0:
+            assert rel(got.rare_event, want.rare_event) < TOL, (kern, got.rare_event, want.rare_event)
+            assert rel(got.mcub, want.mcub) < TOL, (kern, got.mcub, want.mcub)
+        else:
+            assert got.rare_event == want.rare_event and got.mcub == want.mcub
+        # sum-only pass (no per-row outputs) gives the same scalars
+        got2 = ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order, kernel=kern))
+        assert (got2.rare_event, got2.mcub, got2.n_kept, got2.argmax_row) == (got.rare_event, got.mcub, got.n_kept,
+                                                                              got.argmax_row)
+    model.close()
+    return want
+
+
+# ---- known answers and edge cases ------------------------------------------------------------------
+
+def test_known_answers(gpu_ctx, oracle):
+    w = check_against_oracle(gpu_ctx, oracle, *csr([[0, 1, 2]]), np.array([0.1, 0.2, 0.3]), 3, 0.0, 20)
+    assert rel(w.rare_event, 0.006) < 1e-15
+    check_against_oracle(gpu_ctx, oracle, *csr([[0], [1], [2], [3]]), np.array([1e-3, 2e-3, 3e-3, 4e-3]), 4, 0.0, 20)
+    w = check_against_oracle(gpu_ctx, oracle, *csr([[0, 1], [0, 2], [1, 2]]), np.full(3, 0.1), 3, 0.0, 20)
+    assert rel(w.mcub, 0.029701) < 1e-12 and w.argmax_row == 0
+
+
+def test_edge_cases(gpu_ctx, oracle):
+    # empty model
+    check_against_oracle(gpu_ctx, oracle, np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.array([0.5]), 1,
+                         1e-8, 20)
+    # empty rows, certain (p=1) and impossible (p=0) events
+    check_against_oracle(gpu_ctx, oracle, *csr([[], [0], [], [1, 2], [3]]), np.array([0.5, 1.0, 1.0, 0.0]), 4, 0.0, 20)
+    check_against_oracle(gpu_ctx, oracle, *csr([[3], [0, 3]]), np.array([0.5, 1.0, 1.0, 0.0]), 4, 1e-8, 20)
+    # cut-off boundary: p == cut_off is kept, just below is dropped
+    cut = 1e-8
+    check_against_oracle(gpu_ctx, oracle, *csr([[0], [1], [2], [3, 4]]),
+                         np.array([cut, cut * (1 - 1e-12), cut * (1 + 1e-12), 1e-4, 1e-4]), 5, cut, 20)
+    # limit_order
+    check_against_oracle(gpu_ctx, oracle, *csr([[0, 1, 2], [0, 1], [3, 4, 5], [5]]), np.full(6, 0.5), 6, 0.0, 2)
+
+
+def test_ragged_and_long_rows(gpu_ctx, oracle):
+    rng = np.random.default_rng(7)
+    n_events = 5000
+    rows = []
+    for i in range(3000):
+        ln = int(rng.choice([0, 1, 2, 5, 17, 40, 300, 4000], p=[.05, .2, .3, .3, .1, .03, .015, .005]))
+        rows.append(np.sort(rng.choice(n_events, size=ln, replace=False)).tolist())
+    p = rng.uniform(0.3, 1.0, size=n_events)  # long rows must not all underflow
+    check_against_oracle(gpu_ctx, oracle, *csr(rows), p, n_events, 1e-30, 0)
+    check_against_oracle(gpu_ctx, oracle, *csr(rows), p, n_events, 1e-6, 20)
+
+
+def test_row_counts_around_slab_and_wave_sizes(gpu_ctx, oracle):
+    p = oracle.synth_probabilities(SEED, 1000)
+    for n in (1, 63, 64, 65, 255, 256, 257, 1023, 4097):
+        row_ptr, col = oracle.synth_csr(SEED, n, 1000, 4)
+        check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, 1000, 0.0, 20)
+
+
+def test_invalid_models_and_arguments_are_rejected(gpu_ctx):
+    from canopy_amd import _capi
+    bad = [
+        (np.array([0, 2, 1], dtype=np.int64), np.array([0, 1], dtype=np.int32)),   # row_ptr not monotone
+        (np.array([0, 2], dtype=np.int64), np.array([1, 0], dtype=np.int32)),      # not ascending
+        (np.array([0, 2], dtype=np.int64), np.array([1, 1], dtype=np.int32)),      # duplicate
+        (np.array([0, 1], dtype=np.int64), np.array([7], dtype=np.int32)),         # out of range
+        (np.array([0, 1], dtype=np.int64), np.array([-1], dtype=np.int32)),        # negative
+        (np.array([0, 5, 2], dtype=np.int64), np.array([0, 1], dtype=np.int32)),   # row_ptr past nnz
+    ]
+    for row_ptr, col in bad:
+        with pytest.raises(_capi.CanopyError) as e:
+            gpu_ctx.upload(row_ptr, col, 3)
+        assert e.value.status == _capi.ERR_INVALID_MODEL
+    m = gpu_ctx.upload(*csr([[0]]), 1)
+    with pytest.raises(_capi.CanopyError) as e:
+        gpu_ctx.quantify(m)  # probabilities not set
+    assert e.value.status == _capi.ERR_STATE
+    with pytest.raises(_capi.CanopyError) as e:
+        m.set_probabilities(np.array([1.5]))
+    assert e.value.status == _capi.ERR_INVALID_ARGUMENT
+    m.close()
+
+
+# ---- golden vectors ------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("idx", range(6))
+def test_against_mpmath_golden(gpu_ctx, idx):
+    from canopy_amd import default_params
+    with open(GOLD) as f:
+        g = json.load(f)
+    c = g["cases"][idx]
+    model = gpu_ctx.synthetic(g["seed"], c["n_rows"], g["n_events"], c["avg"], first_row=c["first_row"])
+    model.set_probabilities(np.array([float.fromhex(x) for x in g["p_%s_hex" % c["p"]]]))
+    e = c["expected"]
+    for kern in variants(g["n_events"]):
+        r = gpu_ctx.quantify(model, default_params(cut_off=c["cut_off"], limit_order=c["limit_order"], kernel=kern))
+        assert r.n_kept == e["n_kept"] and r.argmax_row == e["argmax_row"]
+        assert rel(r.rare_event, float(e["rare"])) < 1e-12 and rel(r.mcub, float(e["mcub"])) < 1e-12
+    model.close()
+
+
+# ---- BASELINE configs -----------------------------------------------------------------------------------
+
+def test_synthetic_generator_matches_oracle(gpu_ctx, oracle):
+    for (n, e, avg, first) in ((100000, 1000, 4, 0), (50000, 100000, 6, 0), (4097, 100000, 6, 99990000),
+                               (1000, 64, 17, 5)):
+        m = gpu_ctx.synthetic(SEED, n, e, avg, first_row=first)
+        row_ptr, col = m.download()
+        o_rp, o_col = oracle.synth_csr(SEED, n, e, avg, first_row=first, n_threads=4)
+        assert np.array_equal(row_ptr, o_rp) and np.array_equal(col, o_col)
+        info = m.info()
+        assert info.nnz == o_rp[-1] and info.row_offset == first and info.max_row_len == 2 * avg - 2
+        assert info.algorithmic_bytes == (n + 1) * 8 + info.nnz * 4 + e * 8
+        m.close()
+
+
+@pytest.mark.parametrize("cut_off", [1e-8, 0.0])
+def test_config2_full_parity(gpu_ctx, oracle, cut_off):
+    """BASELINE config 2: 1e5 cut sets x 1e3 events, avg 4 nnz/row."""
+    row_ptr, col = oracle.synth_csr(SEED, 100000, 1000, 4, n_threads=4)
+    p = oracle.synth_probabilities(SEED, 1000)
+    check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, 1000, cut_off, 20)
+
+
+def test_config3_shape_reduced_full_parity(gpu_ctx, oracle):
+    """Config-3 shape (1e5 events, avg 6) at 2e6 rows: full per-row comparison against the oracle."""
+    n = 2_000_000
+    row_ptr, col = oracle.synth_csr(SEED, n, 100000, 6, n_threads=8)
+    p = oracle.synth_probabilities(SEED, 100000)
+    check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, 100000, 1e-12, 20, threads=8)
+    check_against_oracle(gpu_ctx, oracle, row_ptr[:300001] , col[:row_ptr[300000]], p, 100000, 0.0, 5, threads=8)
+
+
+def test_config3_full_size_properties(gpu_ctx, oracle):
+    """BASELINE config 3 at full size (1e8 x 1e5, avg 6): size-independent properties.
+    - sampled row windows: s_i and the keep mask bit-exact against the oracle (counter-based rows)
+    - linearity: two half-models (row ranges) combine to the whole: integers exact, sums <= 1e-12
+    - monotonicity: n_kept(cut_off=0) == R; raising the cut-off only removes rows
+    """
+    from canopy_amd import _capi, combine_partials, default_params
+    n, e, avg = 100_000_000, 100000, 6
+    p = oracle.synth_probabilities(SEED, e)
+    model = gpu_ctx.synthetic(SEED, n, e, avg)
+    model.set_probabilities(p)
+    prm = default_params(cut_off=1e-14, limit_order=20, flags=_capi.QUANT_ROW_LOGP | _capi.QUANT_KEEP_MASK)
+    whole = gpu_ctx.quantify(model, prm)
+    for first in (0, 12_345_600, 49_999_936, 99_990_016):
+        cnt = 9984
+        o_rp, o_col = oracle.synth_csr(SEED, cnt, e, avg, first_row=first, n_threads=4)
+        want = oracle.quantify(o_rp, o_col, p, cut_off=1e-14, limit_order=20)
+        assert np.array_equal(gpu_ctx.fetch_row_logp(model, first, cnt), want.row_logp)
+        assert np.array_equal(gpu_ctx.fetch_keep_mask(model, first // 64, cnt // 64), want.keep_mask)
+    part_whole = gpu_ctx.fetch_partial()
+    all_rows = gpu_ctx.quantify(model, default_params(cut_off=0.0, limit_order=0))
+    assert all_rows.n_kept == n and all_rows.n_kept >= whole.n_kept
+    assert 0.05 < all_rows.rare_event < 0.12  # ~0.08 at config 3
+    assert all_rows.mcub < all_rows.rare_event
+    model.close()
+    parts = []
+    kept = 0
+    for first, cnt in ((0, 37_000_000), (37_000_000, 63_000_000)):
+        m = gpu_ctx.synthetic(SEED, cnt, e, avg, first_row=first)
+        m.set_probabilities(p)
+        gpu_ctx.quantify_async(m, default_params(cut_off=1e-14, limit_order=20))
+        parts.append(gpu_ctx.fetch_partial())
+        kept += int(parts[-1].n_kept)
+        m.close()
+    both = combine_partials(parts)
+    assert both.n_kept == whole.n_kept == kept and both.argmax_row == whole.argmax_row
+    assert both.max_logp == whole.max_logp
+    assert rel(both.rare_event, whole.rare_event) < TOL and rel(both.mcub, whole.mcub) < TOL
+    assert part_whole.n_kept == whole.n_kept
