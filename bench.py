@@ -97,6 +97,11 @@ def main():
     info = model.info()
     t_build = time.time() - t0
     prm = canopy_amd.default_params(cut_off=args.cut_off, limit_order=20, kernel=args.kernel)
+    t0 = time.time()
+    model.prepare(args.kernel)  # one-off derived layout (wave-slab stream) for the variant that will run
+    ctx.synchronize()
+    t_prepare = time.time() - t0
+    info = model.info()
     comb = ShardCombiner(ctx=ctx) if world > 1 else None
 
     def step():
@@ -163,11 +168,11 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "k_rows (K1-K4 fused)", "algorithmic_bytes_per_launch": info.algorithmic_bytes,
                 "bytes_per_cut_set": info.algorithmic_bytes / max(info.n_rows, 1),
-                "avg_kernel_ms": k_ms, "avg_pass_ms": tot_ms_sum / max(n_timed, 1), "launches_timed": n_timed,
+                "stream_bytes_per_launch": info.stream_bytes, "avg_kernel_ms": k_ms, "avg_pass_ms": tot_ms_sum / max(n_timed, 1), "launches_timed": n_timed,
             },
             "result": {"rare_event": result.rare_event, "mcub": result.mcub, "n_kept": result.n_kept,
                        "argmax_row": result.argmax_row},
-            "model_build_s": t_build,
+            "model_build_s": t_build, "model_prepare_s": t_prepare,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ctx, canopy_amd, args.events, args.avg_nnz, p, args.cpu_sample_rows)

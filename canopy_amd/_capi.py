@@ -27,7 +27,7 @@ UPLOAD_DEVICE_POINTERS = 2
 
 APPROX_RARE_EVENT, APPROX_MCUB, APPROX_BOTH = 1, 2, 3
 QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK = 1, 2, 4
-KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS = 0, 1, 2
+KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM = 0, 1, 2, 3
 
 
 class CtxParams(C.Structure):
@@ -42,7 +42,7 @@ class CsrView(C.Structure):
 class ModelInfo(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("nnz", C.c_int64), ("row_offset", C.c_int64),
                 ("n_events", C.c_int32), ("max_row_len", C.c_int32),
-                ("device_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64)]
+                ("device_bytes", C.c_int64), ("stream_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64)]
 
 
 class QuantParams(C.Structure):
@@ -76,6 +76,7 @@ SIGNATURES = {
     "canopy_model_get_info": (C.c_int, [C.c_void_p, C.POINTER(ModelInfo)]),
     "canopy_model_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "canopy_model_set_probabilities": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "canopy_model_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "canopy_quant_params_default": (None, [C.POINTER(QuantParams)]),
     "canopy_quantify_async": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QuantParams)]),
     "canopy_quantify_fetch": (C.c_int, [C.c_void_p, C.POINTER(Partial)]),

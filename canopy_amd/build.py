@@ -12,12 +12,13 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcanopy.so")
 
-SOURCES = ["canopy_api.hip", "kernels_rows.hip", "kernels_build.hip"]
+SOURCES = ["canopy_api.hip", "kernels_rows.hip", "kernels_build.hip", "kernels_ws.hip"]
 HEADERS = ["canopy_device.h", "canopy_internal.h"]
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off",          # s_i must be a chain of plain IEEE adds (bit-exact vs the oracle)
+    "-munsafe-fp-atomics",        # LDS fp64 add as one ds_add_f64 (IEEE add; bit-exactness is tested)
     "-fvisibility=hidden", "-DCANOPY_BUILD", "-DCANOPY_SHARED",
 ]
 

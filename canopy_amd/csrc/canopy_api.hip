@@ -52,7 +52,10 @@ void free_model_buffers(canopy_model* m) {
     if (m->d_row_ptr) (void)hipFree(m->d_row_ptr);
     if (m->d_col_idx) (void)hipFree(m->d_col_idx);
     if (m->d_logp) (void)hipFree(m->d_logp);
+    if (m->d_ws_stream) (void)hipFree(m->d_ws_stream);
+    if (m->d_ws_off) (void)hipFree(m->d_ws_off);
     m->d_row_ptr = nullptr; m->d_col_idx = nullptr; m->d_logp = nullptr;
+    m->d_ws_stream = nullptr; m->d_ws_off = nullptr; m->ws_state = 0;
 }
 
 } // namespace
@@ -288,6 +291,7 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
     info->n_rows = m->n_rows; info->nnz = m->nnz; info->row_offset = m->row_offset;
     info->n_events = m->n_events; info->max_row_len = m->max_row_len;
     info->device_bytes = m->device_bytes;
+    info->stream_bytes = m->ws_state == 1 ? m->ws_total_chunks * 1024 + (m->n_ws + 1) * 8 + (int64_t)m->n_events * 8 : 0;
     info->algorithmic_bytes = (m->n_rows + 1) * 8 + m->nnz * 4 + (int64_t)m->n_events * 8;
     return CANOPY_OK;
 }
@@ -316,6 +320,44 @@ canopy_status canopy_model_set_probabilities(canopy_ctx* ctx, canopy_model* m, c
     return CANOPY_OK;
 }
 
+// ---- derived layouts -----------------------------------------------------------------------------
+
+namespace {
+
+// What AUTO resolves to for this model (before knowing whether the WS build succeeds).
+int auto_variant(const canopy_model* m) {
+    if ((size_t)m->n_events <= rows_lds_table_limit_events()) return CANOPY_KERNEL_ROWS_LDS;
+    if (m->n_events <= ws_max_events()) return CANOPY_KERNEL_WAVE_STREAM;
+    return CANOPY_KERNEL_ROWS;
+}
+
+canopy_status build_ws(canopy_ctx* ctx, canopy_model* m) {
+    if (m->ws_state != 0) return CANOPY_OK;
+    if (m->n_events > ws_max_events()) { m->ws_state = -1; return CANOPY_OK; }
+    bool ok = false;
+    HIP_TRY(ctx, ws_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, m->max_row_len, &m->d_ws_stream,
+                          &m->d_ws_off, &m->ws_total_chunks, &m->n_ws, &ok, ctx->stream));
+    m->ws_state = ok ? 1 : -1;
+    if (ok) m->device_bytes += (m->ws_total_chunks + 1) * 1024 + (m->n_ws + 1) * 8;
+    return CANOPY_OK;
+}
+
+} // namespace
+
+extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, int32_t kernel) {
+    if (!ctx || !m) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (m->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "model lives on another device");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int variant = kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : kernel;
+    if (variant == CANOPY_KERNEL_ROWS || variant == CANOPY_KERNEL_ROWS_LDS) return CANOPY_OK;
+    if (variant != CANOPY_KERNEL_WAVE_STREAM) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
+    canopy_status st = build_ws(ctx, m);
+    if (st != CANOPY_OK) return st;
+    if (m->ws_state != 1 && kernel == CANOPY_KERNEL_WAVE_STREAM)
+        return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a wave-slab stream");
+    return CANOPY_OK;
+}
+
 // ---- quantification ----------------------------------------------------------------------------
 
 canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, const canopy_quant_params* params) {
@@ -328,13 +370,20 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "limit_order < 0 or cut_off < 0");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    int variant = params->kernel;
-    if (variant == CANOPY_KERNEL_AUTO)
-        variant = ((size_t)m->n_events <= rows_lds_table_limit_events()) ? CANOPY_KERNEL_ROWS_LDS : CANOPY_KERNEL_ROWS;
-    if (variant != CANOPY_KERNEL_ROWS && variant != CANOPY_KERNEL_ROWS_LDS)
+    int variant = params->kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : params->kernel;
+    if (variant != CANOPY_KERNEL_ROWS && variant != CANOPY_KERNEL_ROWS_LDS && variant != CANOPY_KERNEL_WAVE_STREAM)
         return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
     if (variant == CANOPY_KERNEL_ROWS_LDS && (size_t)m->n_events > rows_lds_table_limit_events())
         return fail(ctx, CANOPY_ERR_UNSUPPORTED, "logp table does not fit the LDS budget of ROWS_LDS");
+    if (variant == CANOPY_KERNEL_WAVE_STREAM) {
+        canopy_status pst = build_ws(ctx, const_cast<canopy_model*>(m)); // lazy, one-off, independent of p
+        if (pst != CANOPY_OK) return pst;
+        if (m->ws_state != 1) {
+            if (params->kernel == CANOPY_KERNEL_WAVE_STREAM)
+                return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a wave-slab stream");
+            variant = CANOPY_KERNEL_ROWS;
+        }
+    }
 
     const bool want_rows = (params->flags & CANOPY_QUANT_ROW_LOGP) != 0;
     const bool want_mask = (params->flags & CANOPY_QUANT_KEEP_MASK) != 0;
@@ -352,7 +401,11 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         ctx->keep_mask_cap = n_words;
     }
 
-    int grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override
+    int grid;
+    if (variant == CANOPY_KERNEL_WAVE_STREAM)
+        grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : ws_default_grid(ctx->n_cu, m->n_ws);
+    else
+        grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override
                                           : rows_kernel_default_grid(ctx->n_cu, variant, m->n_rows);
     canopy_status st = ensure_block_partials(ctx, grid);
     if (st != CANOPY_OK) return st;
@@ -372,7 +425,13 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         ++ctx->timing_n;
     }
     HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
-    HIP_TRY(ctx, launch_rows_kernel(variant, a, grid, ctx->stream));
+    if (variant == CANOPY_KERNEL_WAVE_STREAM) {
+        const int need_len = (params->limit_order != 0 && params->limit_order < m->max_row_len) ? 1 : 0;
+        HIP_TRY(ctx, launch_ws_kernel(a, m->d_ws_stream, m->d_ws_off, m->ws_total_chunks, m->n_ws, need_len, grid,
+                                      ctx->stream));
+    } else {
+        HIP_TRY(ctx, launch_rows_kernel(variant, a, grid, ctx->stream));
+    }
     HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     HIP_TRY(ctx, launch_finalize(ctx->d_block_partials, grid, ctx->d_partial, ctx->d_gather, ctx->gather_world,
                                  ctx->gather_rank, ctx->stream));

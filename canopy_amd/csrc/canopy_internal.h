@@ -49,6 +49,11 @@ struct canopy_model {
     double* d_logp = nullptr;     // [n_events]
     bool has_p = false;
     int64_t device_bytes = 0;
+    // derived wave-slab stream layout (kernels_ws.hip), built by canopy_model_prepare
+    uint32_t* d_ws_stream = nullptr;
+    int64_t* d_ws_off = nullptr;
+    int64_t ws_total_chunks = 0, n_ws = 0;
+    int ws_state = 0; // 0 not built, 1 ready, -1 not representable (fall back to ROWS)
 };
 
 namespace canopy {
@@ -79,8 +84,20 @@ hipError_t launch_validate_csr(const int64_t* row_ptr, const int32_t* col_idx, i
                                int64_t nnz, int32_t n_events, int64_t* d_status /*[2]: first bad row, max len*/,
                                hipStream_t s);
 hipError_t launch_rebase_row_ptr(int64_t* row_ptr, int64_t n_plus_1, int64_t base, hipStream_t s);
+hipError_t scan_inclusive_i64(int64_t* data, int64_t n, hipStream_t s);
 hipError_t synth_build_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int32_t n_events,
                            int32_t avg_nnz, int64_t** d_row_ptr_out, int32_t** d_col_idx_out,
                            int64_t* nnz_out, hipStream_t s);
+
+
+// kernels_ws.hip
+int ws_rows_per_wave();
+int ws_max_events();
+int ws_default_grid(int n_cu, int64_t n_ws);
+hipError_t ws_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events,
+                    int32_t max_row_len, uint32_t** d_stream_out, int64_t** d_ws_off_out,
+                    int64_t* total_chunks_out, int64_t* n_ws_out, bool* ok, hipStream_t s);
+hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, const int64_t* ws_off,
+                            int64_t total_chunks, int64_t n_ws, int need_len, int grid, hipStream_t s);
 
 } // namespace canopy

@@ -145,6 +145,8 @@ int grid_for(int64_t n, int block) {
 
 } // namespace
 
+hipError_t scan_inclusive_i64(int64_t* data, int64_t n, hipStream_t s) { return scan_inclusive(data, n, s); }
+
 hipError_t launch_validate_csr(const int64_t* row_ptr, const int32_t* col_idx, int64_t n_rows, int64_t nnz,
                                int32_t n_events, int64_t* d_status, hipStream_t s) {
     hipLaunchKernelGGL(k_validate, dim3(grid_for(n_rows, 256)), dim3(256), 0, s, row_ptr, col_idx, n_rows, nnz,

@@ -166,6 +166,10 @@ class Model:
                    "canopy_model_download", self._ctx.handle)
         return row_ptr, col_idx
 
+    def prepare(self, kernel=capi.KERNEL_AUTO):
+        capi.check(capi.lib().canopy_model_prepare(self._ctx.handle, self._h, kernel), "canopy_model_prepare",
+                   self._ctx.handle)
+
     def set_probabilities(self, p):
         p = _as(p, np.float64)
         if p.shape != (self.info().n_events,):

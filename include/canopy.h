@@ -134,7 +134,8 @@ typedef struct canopy_model_info {
     int64_t row_offset;
     int32_t n_events;
     int32_t max_row_len;
-    int64_t device_bytes;       /* bytes of HBM the model holds */
+    int64_t device_bytes;       /* bytes of HBM the model holds (canonical CSR + derived layouts) */
+    int64_t stream_bytes;       /* bytes one pass of the wave-stream kernel reads, 0 if not built */
     int64_t algorithmic_bytes;  /* (R+1)*8 + nnz*4 + E*8: compulsory traffic of one sum-only pass */
 } canopy_model_info;
 
@@ -151,6 +152,15 @@ CANOPY_API canopy_status canopy_model_download(canopy_ctx* ctx, const canopy_mod
  */
 CANOPY_API canopy_status canopy_model_set_probabilities(canopy_ctx* ctx, canopy_model* model,
                                                         const double* p);
+
+/*
+ * Build the derived device layout a kernel variant needs (today: the wave-slab stream of
+ * CANOPY_KERNEL_WAVE_STREAM; a no-op for the others). One-off per model, independent of p.
+ * kernel = CANOPY_KERNEL_AUTO prepares what AUTO will pick. canopy_quantify_async prepares lazily
+ * (and synchronously) when this was not called. Returns CANOPY_ERR_UNSUPPORTED if the variant was
+ * asked for explicitly and the model cannot be represented in it (E >= 2^19 or absurd row lengths).
+ */
+CANOPY_API canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* model, int32_t kernel);
 
 /* ---- quantification ------------------------------------------------------------------------ */
 typedef enum canopy_approximation { /* reference settings.h:19 Approximation */
@@ -176,7 +186,9 @@ typedef struct canopy_quant_params {
 enum {
     CANOPY_KERNEL_AUTO = 0,
     CANOPY_KERNEL_ROWS = 1,     /* lane-per-row, LDS-staged col_idx slab, logp gathered via L2 */
-    CANOPY_KERNEL_ROWS_LDS = 2  /* same, logp table resident in LDS (needs E*8 B <= table budget) */
+    CANOPY_KERNEL_ROWS_LDS = 2, /* same, logp table resident in LDS (needs E*8 B <= table budget) */
+    CANOPY_KERNEL_WAVE_STREAM = 3 /* derived layout: per-wave column-ordered entry stream, row sums in
+                                     LDS (large E); built once by canopy_model_prepare */
 };
 
 CANOPY_API void canopy_quant_params_default(canopy_quant_params* params);

@@ -30,6 +30,8 @@ def variants(n_events):
     v = [_capi.KERNEL_ROWS]
     if n_events <= 12288:
         v.append(_capi.KERNEL_ROWS_LDS)
+    if n_events <= (1 << 19):
+        v.append(_capi.KERNEL_WAVE_STREAM)
     return v
 
 
