@@ -407,7 +407,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     else
         grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override
                                           : rows_kernel_default_grid(ctx->n_cu, variant, m->n_rows);
-    canopy_status st = ensure_block_partials(ctx, grid);
+    canopy_status st = ensure_block_partials(ctx, variant == CANOPY_KERNEL_WAVE_STREAM ? grid * 4 : grid);
     if (st != CANOPY_OK) return st;
 
     RowKernelArgs a;
@@ -424,16 +424,17 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         ev = &ctx->ev_pool[(size_t)ctx->timing_n * 3];
         ++ctx->timing_n;
     }
+    int n_records = grid;
     HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
     if (variant == CANOPY_KERNEL_WAVE_STREAM) {
         const int need_len = (params->limit_order != 0 && params->limit_order < m->max_row_len) ? 1 : 0;
         HIP_TRY(ctx, launch_ws_kernel(a, m->d_ws_stream, m->d_ws_off, m->ws_total_chunks, m->n_ws, need_len, grid,
-                                      ctx->stream));
+                                      &n_records, ctx->stream));
     } else {
         HIP_TRY(ctx, launch_rows_kernel(variant, a, grid, ctx->stream));
     }
     HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
-    HIP_TRY(ctx, launch_finalize(ctx->d_block_partials, grid, ctx->d_partial, ctx->d_gather, ctx->gather_world,
+    HIP_TRY(ctx, launch_finalize(ctx->d_block_partials, n_records, ctx->d_partial, ctx->d_gather, ctx->gather_world,
                                  ctx->gather_rank, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     if (ev == ctx->ev_last) ctx->last_timed = true;

@@ -98,6 +98,7 @@ hipError_t ws_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
                     int32_t max_row_len, uint32_t** d_stream_out, int64_t** d_ws_off_out,
                     int64_t* total_chunks_out, int64_t* n_ws_out, bool* ok, hipStream_t s);
 hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, const int64_t* ws_off,
-                            int64_t total_chunks, int64_t n_ws, int need_len, int grid, hipStream_t s);
+                            int64_t total_chunks, int64_t n_ws, int need_len, int grid, int* n_records,
+                            hipStream_t s);
 
 } // namespace canopy

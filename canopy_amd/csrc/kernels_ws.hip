@@ -21,6 +21,8 @@
 // Stream layout: chunk = 256 entries = 4 groups; group g of a wave-slab is chunk g/4, and its
 // slot k (0..63) sits at entry index 4*k + (g%4) of the chunk, so lane k's 16-byte load brings its
 // entry of each of the chunk's 4 groups. Unused slots hold the no-op entry (col 0, row_local RW).
+#include <stdlib.h>
+
 #include "canopy_device.h"
 #include "canopy_internal.h"
 
@@ -35,7 +37,8 @@ constexpr int kChunk = 256; // entries per chunk (one uint4 per lane)
 
 template <int RW>
 struct WsCfg {
-    static_assert(RW <= 4096 && (RW % 64) == 0, "row_local needs RW < 2^13 with the sink slot");
+    static_assert(RW <= 8192 && (RW % 64) == 0, "row_local needs RW < 2^(row_bits) with the sink slot");
+    static constexpr int row_bits = RW > 4096 ? 14 : 13;
     static constexpr int waves = 16384 / RW;     // per workgroup = per CU
     static constexpr int slots = RW + 64;        // sink at RW (.. RW+63 unused padding)
     static constexpr size_t lds_bytes = (size_t)waves * slots * 8;
@@ -49,7 +52,7 @@ struct WsCfg {
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_ws_build(const int64_t* __restrict__ row_ptr,
                                                  const int32_t* __restrict__ col_idx, int64_t n_rows,
-                                                 int32_t n_events, int rw, int64_t n_ws, int gcap,
+                                                 int32_t n_events, int rw, int row_bits, int64_t n_ws, int gcap,
                                                  uint8_t* cnt_scratch, int64_t* chunks /* [n_ws] out (count pass) */,
                                                  const int64_t* __restrict__ ws_off, uint32_t* stream,
                                                  int* overflow) {
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(64) void k_ws_build(const int64_t* __restrict__ row
             while (g < gcap && cnt[g] >= kGroup) ++g;
             if (g >= gcap) { ovf = true; break; }
             const int slot = cnt[g]++;
-            if (WRITE) stream[base + (int64_t)(g >> 2) * kChunk + slot * 4 + (g & 3)] = (c << kRowBits) | (uint32_t)(r - r0);
+            if (WRITE) stream[base + (int64_t)(g >> 2) * kChunk + slot * 4 + (g & 3)] = (c << row_bits) | (uint32_t)(r - r0);
             g_prev = g;
             g_max = g > g_max ? g : g_max;
         }
@@ -107,33 +110,63 @@ __device__ __forceinline__ int64_t uload_i64(const int64_t* __restrict__ p) {
     return (int64_t)(((uint64_t)hi << 32) | (uint64_t)lo);
 }
 
-// Fold the RW finished row sums of one wave-slab (exp / log1p / filters / outputs) and clear them.
+// Fold the RW finished row sums of one wave-slab and clear them. Two passes:
+//   1. per row: filter decision, count, argmax, optional outputs (cheap, every lane busy); the kept
+//      s_i are compacted to the front of the wave's own sums slice;
+//   2. exp / log1p / compensated sums over the compacted list only, 64 kept rows per instruction.
+// (With the default cut-off < 1 % of the rows survive: the transcendental work all but vanishes.)
 template <int RW>
 __device__ __noinline__ void ws_epilogue(double* sums, int64_t t, int lane, Acc* acc_io, int64_t n_rows,
                                          int64_t row_offset, double log_cut, int limit_order, int need_len,
-                                         const int64_t* row_ptr, double* row_logp_out, uint64_t* keep_mask_out) {
+                                         const int64_t* row_ptr, double* row_logp_out, uint64_t* keep_mask_out,
+                                         int it_begin, int it_end) {
+    // rows [it_begin*64, it_end*64) of the wave-slab are this wave's share; it compacts into the front
+    // of its own share only
     Acc acc = *acc_io;
-#pragma unroll 2
-    for (int i = 0; i < RW / kWave; ++i) {
-        const int rl = i * kWave + lane;
-        const int64_t r = t * RW + rl;
-        const bool valid = r < n_rows;
-        const double s = sums[rl];
-        sums[rl] = 0.0;
-        int len = 0;
-        if (need_len && valid) len = (int)(row_ptr[r + 1] - row_ptr[r]);
-        const bool keep = row_epilogue(acc, s, len, valid, log_cut, limit_order, (double)(row_offset + r));
-        if (row_logp_out != nullptr && valid) row_logp_out[r] = s;
-        if (keep_mask_out != nullptr) {
+    const int comp_base = it_begin * kWave;
+    int n_comp = 0; // wave-uniform
+    constexpr int U = 4;
+    for (int i0 = it_begin; i0 < it_end; i0 += U) {
+        double s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] = sums[(i0 + u) * kWave + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u) sums[(i0 + u) * kWave + lane] = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = t * RW + (i0 + u) * kWave + lane;
+            const bool valid = r < n_rows;
+            int len = 0;
+            if (need_len && valid) len = (int)(row_ptr[r + 1] - row_ptr[r]);
+            const bool keep = valid && (s[u] >= log_cut) && (limit_order == 0 || len <= limit_order);
             const unsigned long long m = __ballot(keep);
-            if (lane == 0 && r < n_rows) keep_mask_out[r >> 6] = m;
+            if (keep) {
+                acc.n_kept += 1.0;
+                if (s[u] > acc.max_logp) { acc.max_logp = s[u]; acc.argmax = (double)(row_offset + r); }
+                const int pos = comp_base + n_comp +
+                                (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                sums[pos] = s[u]; // pos <= this row's own slot, already read and cleared above
+            }
+            n_comp += __builtin_popcountll(m);
+            if (row_logp_out != nullptr && valid) row_logp_out[r] = s[u];
+            if (keep_mask_out != nullptr && lane == 0 && r < n_rows) keep_mask_out[r >> 6] = m;
         }
     }
-    sums[RW + lane] = 0.0; // the sink
+    for (int j = 0; j < n_comp; j += kWave) {
+        const bool on = j + lane < n_comp;
+        const double sv = on ? sums[comp_base + j + lane] : 0.0;
+        if (on) {
+            sums[comp_base + j + lane] = 0.0;
+            const double P = exp(sv);
+            csum_add(acc.rare, P);
+            if (P < 1.0) csum_add(acc.l1p, log1p(-P)); else acc.n_certain += 1.0;
+        }
+    }
+    if (it_begin == 0) sums[RW + lane] = 0.0; // the sink
     *acc_io = acc;
 }
 
-template <int RW, int D>
+template <int RW, int D, int ABL>
 __global__ __launch_bounds__(WsCfg<RW>::waves * kWave) void k_ws(const uint4* __restrict__ stream,
                                                                  const int64_t* __restrict__ ws_off,
                                                                  const double* __restrict__ logp,
@@ -156,58 +189,64 @@ __global__ __launch_bounds__(WsCfg<RW>::waves * kWave) void k_ws(const uint4* __
     int64_t t = (int64_t)blockIdx.x * C::waves + wave; // wave-uniform (SGPRs)
 
     if (t < sc.n_ws) {
-        // Load side: walks the same sequence of wave-slabs as the processing side, one batch (D
-        // chunks) ahead. vmcnt retires in order, so a wave cannot hide HBM stream loads behind its
-        // own gather waits: it issues a whole batch, stalls once for it (the other waves of the CU
-        // own the memory pipes meanwhile), then runs D steps with counted gather waits only.
+        // Per batch of D chunks: (G) issue ALL 4*D gathers of the batch, (L) issue the D stream loads
+        // of the NEXT batch into the other register set, (A) the LDS adds. vmcnt retires in order:
+        // the adds wait only for gathers, which are OLDER than the stream loads just issued, so the
+        // HBM loads stay in flight under the whole add phase (and under the other waves' work).
         int64_t lt = t;
         int64_t lp = uload_i64(ws_off + lt), lp_end = uload_i64(ws_off + lt + 1);
         int64_t rem = lp_end - lp;
-        uint4 q[D];
+        uint4 q[2][D];
+        double v[D][4];
         bool done = false;
-        while (!done) {
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                while (lp == lp_end) { // skip wave-slabs without entries; past the end: the no-op chunk
-                    lt += GW;
-                    if (lt < sc.n_ws) { lp = uload_i64(ws_off + lt); lp_end = uload_i64(ws_off + lt + 1); }
-                    else { lp = sc.total_chunks; lp_end = sc.total_chunks + 1; break; }
-                }
-                q[k] = stream[lp * kWave + lane];
-                ++lp;
-            }
-            double v[2][4];
-            {
-                const uint32_t e[4] = {q[0].x, q[0].y, q[0].z, q[0].w};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[0][u] = logp[e[u] >> kRowBits];
-            }
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                if (k + 1 < D) { // gathers run one chunk ahead of the LDS adds (read-only table)
-                    const uint32_t en[4] = {q[k + 1].x, q[k + 1].y, q[k + 1].z, q[k + 1].w};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[(k + 1) & 1][u] = logp[en[u] >> kRowBits];
-                }
-                if (!done) {
-                    while (rem == 0) { // wave-slab finished (or empty): fold its rows, move on
-                        ws_epilogue<RW>(sums, t, lane, &acc, sc.n_rows, sc.row_offset, sc.log_cut, sc.limit_order,
-                                        sc.need_len, row_ptr, row_logp_out, keep_mask_out);
-                        t += GW;
-                        if (t >= sc.n_ws) { done = true; break; }
-                        rem = uload_i64(ws_off + t + 1) - uload_i64(ws_off + t);
-                    }
-                }
-                if (!done) {
-                    const uint32_t ec[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        __hip_atomic_fetch_add(&sums[ec[u] & kRowMask], v[k & 1][u], __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    --rem;
-                }
-            }
+#define WS_LOAD_BATCH(QB)                                                                              \
+        _Pragma("unroll") for (int k = 0; k < D; ++k) {                                                \
+            while (lp == lp_end) { /* skip wave-slabs without entries; past the end: the no-op chunk */ \
+                lt += GW;                                                                              \
+                if (lt < sc.n_ws) { lp = uload_i64(ws_off + lt); lp_end = uload_i64(ws_off + lt + 1); } \
+                else { lp = sc.total_chunks; lp_end = sc.total_chunks + 1; break; }                     \
+            }                                                                                          \
+            QB[k] = stream[lp * kWave + lane];                                                         \
+            ++lp;                                                                                      \
         }
+#define WS_BATCH(QC, QN)                                                                               \
+        if (!done) {                                                                                   \
+            _Pragma("unroll") for (int k = 0; k < D; ++k) {                                            \
+                const uint32_t e[4] = {QC[k].x, QC[k].y, QC[k].z, QC[k].w};                            \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u)                                          \
+                    v[k][u] = (ABL & 1) ? (double)e[u] : logp[e[u] >> C::row_bits];                       \
+            }                                                                                          \
+            WS_LOAD_BATCH(QN)                                                                          \
+            _Pragma("unroll") for (int k = 0; k < D; ++k) {                                            \
+                if (!done) {                                                                           \
+                    while (rem == 0) { /* wave-slab finished (or empty): fold its rows, move on */     \
+                        if (!(ABL & 4))                                                                \
+                            ws_epilogue<RW>(sums, t, lane, &acc, sc.n_rows, sc.row_offset, sc.log_cut, \
+                                            sc.limit_order, sc.need_len, row_ptr, row_logp_out, keep_mask_out, 0, RW / kWave); \
+                        t += GW;                                                                       \
+                        if (t >= sc.n_ws) { done = true; break; }                                      \
+                        rem = uload_i64(ws_off + t + 1) - uload_i64(ws_off + t);                       \
+                    }                                                                                  \
+                }                                                                                      \
+                if (!done) {                                                                           \
+                    const uint32_t e[4] = {QC[k].x, QC[k].y, QC[k].z, QC[k].w};                        \
+                    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                    \
+                        if (ABL & 2) asm volatile("" ::"v"(v[k][u]), "v"(e[u]));                       \
+                        else                                                                           \
+                            __hip_atomic_fetch_add(&sums[e[u] & ((1u << C::row_bits) - 1)], v[k][u], __ATOMIC_RELAXED,  \
+                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);                      \
+                    }                                                                                  \
+                    --rem;                                                                             \
+                }                                                                                      \
+            }                                                                                          \
+        }
+        WS_LOAD_BATCH(q[0])
+        while (!done) {
+            WS_BATCH(q[0], q[1])
+            WS_BATCH(q[1], q[0])
+        }
+#undef WS_BATCH
+#undef WS_LOAD_BATCH
     }
 
     // workgroup reduce of the wave records (the sums slices are dead now)
@@ -236,11 +275,15 @@ int grid_for(int64_t n, int block) {
 
 } // namespace
 
-int ws_rows_per_wave() { return 4096; }
-int ws_max_events() { return 1 << (32 - kRowBits); }
+int ws_rows_per_wave() {
+    static const int dbg = getenv("CANOPY_WS_DEBUG") ? atoi(getenv("CANOPY_WS_DEBUG")) : 0;
+    (void)dbg;
+    return 4096;
+}
+int ws_max_events() { return 1 << (32 - (ws_rows_per_wave() > 4096 ? 14 : 13)); }
 
 int ws_default_grid(int n_cu, int64_t n_ws) {
-    const int waves = WsCfg<4096>::waves;
+    const int waves = 16384 / ws_rows_per_wave();
     int64_t g = (n_ws + waves - 1) / waves;
     if (g > n_cu) g = n_cu;
     if (g < 1) g = 1;
@@ -294,7 +337,7 @@ hipError_t ws_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     e = hipMemsetAsync(d_off, 0, sizeof(int64_t), s);
     if (e != hipSuccess) return bail(e);
     hipLaunchKernelGGL((k_ws_build<false>), dim3(grid_for(n_ws, 64)), dim3(64), 0, s, d_row_ptr, d_col_idx, n_rows,
-                       n_events, rw, n_ws, gcap, d_cnt, d_off + 1, (const int64_t*)nullptr, (uint32_t*)nullptr, d_ovf);
+                       n_events, rw, rw > 4096 ? 14 : 13, n_ws, gcap, d_cnt, d_off + 1, (const int64_t*)nullptr, (uint32_t*)nullptr, d_ovf);
     e = hipGetLastError();
     if (e == hipSuccess) e = scan_inclusive_i64(d_off + 1, n_ws, s);
     int ovf = 0;
@@ -310,7 +353,7 @@ hipError_t ws_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n_entries, 256) > 4096 ? 4096 : grid_for(n_entries, 256)), dim3(256), 0, s,
                        d_stream, n_entries, (uint32_t)rw);
     hipLaunchKernelGGL((k_ws_build<true>), dim3(grid_for(n_ws, 64)), dim3(64), 0, s, d_row_ptr, d_col_idx, n_rows,
-                       n_events, rw, n_ws, gcap, d_cnt, (int64_t*)nullptr, (const int64_t*)d_off, d_stream, d_ovf);
+                       n_events, rw, rw > 4096 ? 14 : 13, n_ws, gcap, d_cnt, (int64_t*)nullptr, (const int64_t*)d_off, d_stream, d_ovf);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return bail(e);
@@ -323,25 +366,43 @@ hipError_t ws_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     return hipSuccess;
 }
 
-hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, const int64_t* ws_off,
-                            int64_t total_chunks, int64_t n_ws, int need_len, int grid, hipStream_t s) {
-    constexpr int RW = 4096, D = 32;
+namespace {
+template <int RW, int D, int ABL>
+hipError_t launch_ws_t(const RowKernelArgs& ra, const uint32_t* stream, const int64_t* ws_off, const WsScalars& sc,
+                       int grid, hipStream_t s) {
     using C = WsCfg<RW>;
-    WsScalars sc;
-    sc.total_chunks = total_chunks;
-    sc.n_rows = ra.n_rows; sc.n_ws = n_ws; sc.row_offset = ra.row_offset;
-    sc.log_cut = ra.log_cut; sc.limit_order = ra.limit_order; sc.need_len = need_len;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ws<RW, D>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ws<RW, D, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_ws<RW, D>), dim3(grid), dim3(C::waves * kWave), C::lds_bytes, s,
+    hipLaunchKernelGGL((k_ws<RW, D, ABL>), dim3(grid), dim3(C::waves * kWave), C::lds_bytes, s,
                        reinterpret_cast<const uint4*>(stream), ws_off, ra.logp, ra.row_ptr, sc, ra.block_partials,
                        ra.row_logp_out, ra.keep_mask_out);
     return hipGetLastError();
+}
+} // namespace
+
+hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, const int64_t* ws_off,
+                            int64_t total_chunks, int64_t n_ws, int need_len, int grid, int* n_records,
+                            hipStream_t s) {
+    *n_records = grid;
+    WsScalars sc;
+    sc.total_chunks = total_chunks;
+    sc.n_rows = ra.n_rows; sc.n_ws = n_ws; sc.row_offset = ra.row_offset;
+    sc.log_cut = ra.log_cut; sc.limit_order = ra.limit_order; sc.need_len = need_len;
+    // tuning/ablation switch for benchmarks/ experiments only (timing builds produce wrong results)
+    static const int dbg = getenv("CANOPY_WS_DEBUG") ? atoi(getenv("CANOPY_WS_DEBUG")) : 0;
+    switch (dbg) {
+        case 1: return launch_ws_t<4096, 8, 1>(ra, stream, ws_off, sc, grid, s); // no gathers
+        case 2: return launch_ws_t<4096, 8, 2>(ra, stream, ws_off, sc, grid, s); // no LDS adds
+        case 4: return launch_ws_t<4096, 8, 4>(ra, stream, ws_off, sc, grid, s); // no epilogue
+        case 7: return launch_ws_t<4096, 8, 7>(ra, stream, ws_off, sc, grid, s); // stream loads only
+        case 16: return launch_ws_t<4096, 16, 0>(ra, stream, ws_off, sc, grid, s);
+        default: return launch_ws_t<4096, 8, 0>(ra, stream, ws_off, sc, grid, s);
+    }
 }
 
 } // namespace canopy
