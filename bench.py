@@ -166,7 +166,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_rows (K1-K4 fused)", "algorithmic_bytes_per_launch": info.algorithmic_bytes,
+                "kernel": ("k_ws (wave-slab stream, K1-K4 fused)" if info.stream_bytes else "k_rows (K1-K4 fused)"),
+                "algorithmic_bytes_per_launch": info.algorithmic_bytes,
                 "bytes_per_cut_set": info.algorithmic_bytes / max(info.n_rows, 1),
                 "stream_bytes_per_launch": info.stream_bytes, "avg_kernel_ms": k_ms, "avg_pass_ms": tot_ms_sum / max(n_timed, 1), "launches_timed": n_timed,
             },
