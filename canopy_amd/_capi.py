@@ -27,7 +27,7 @@ UPLOAD_DEVICE_POINTERS = 2
 
 APPROX_RARE_EVENT, APPROX_MCUB, APPROX_BOTH = 1, 2, 3
 QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK = 1, 2, 4
-KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER = 0, 1, 2, 3, 4
 
 
 class CtxParams(C.Structure):

@@ -54,6 +54,10 @@ void free_model_buffers(canopy_model* m) {
     if (m->d_logp) (void)hipFree(m->d_logp);
     if (m->d_ws_stream) (void)hipFree(m->d_ws_stream);
     if (m->d_ws_off) (void)hipFree(m->d_ws_off);
+    if (m->d_vs_stream) (void)hipFree(m->d_vs_stream);
+    if (m->d_vs_off) (void)hipFree(m->d_vs_off);
+    if (m->d_vs_slab_row) (void)hipFree(m->d_vs_slab_row);
+    m->d_vs_stream = nullptr; m->d_vs_off = nullptr; m->d_vs_slab_row = nullptr; m->vs_state = 0;
     m->d_row_ptr = nullptr; m->d_col_idx = nullptr; m->d_logp = nullptr;
     m->d_ws_stream = nullptr; m->d_ws_off = nullptr; m->ws_state = 0;
 }
@@ -291,7 +295,11 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
     info->n_rows = m->n_rows; info->nnz = m->nnz; info->row_offset = m->row_offset;
     info->n_events = m->n_events; info->max_row_len = m->max_row_len;
     info->device_bytes = m->device_bytes;
-    info->stream_bytes = m->ws_state == 1 ? m->ws_total_chunks * 1024 + (m->n_ws + 1) * 8 + (int64_t)m->n_events * 8 : 0;
+    info->stream_bytes = 0;
+    if (m->vs_state == 1)
+        info->stream_bytes = m->vs_total_chunks * 1024 + (m->n_slabs + 1) * 16 + (m->n_rows + 1) * 8 + (int64_t)m->n_events * 8;
+    else if (m->ws_state == 1)
+        info->stream_bytes = m->ws_total_chunks * 1024 + (m->n_ws + 1) * 8 + (int64_t)m->n_events * 8;
     info->algorithmic_bytes = (m->n_rows + 1) * 8 + m->nnz * 4 + (int64_t)m->n_events * 8;
     return CANOPY_OK;
 }
@@ -331,6 +339,16 @@ int auto_variant(const canopy_model* m) {
     return CANOPY_KERNEL_ROWS;
 }
 
+canopy_status build_vs(canopy_ctx* ctx, canopy_model* m) {
+    if (m->vs_state != 0) return CANOPY_OK;
+    bool ok = false;
+    HIP_TRY(ctx, vs_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->nnz, m->n_events, m->max_row_len, &m->d_vs_stream,
+                          &m->d_vs_off, &m->d_vs_slab_row, &m->vs_total_chunks, &m->n_slabs, &ok, ctx->stream));
+    m->vs_state = ok ? 1 : -1;
+    if (ok) m->device_bytes += (m->vs_total_chunks + 1) * 1024 + (m->n_slabs + 1) * 16;
+    return CANOPY_OK;
+}
+
 canopy_status build_ws(canopy_ctx* ctx, canopy_model* m) {
     if (m->ws_state != 0) return CANOPY_OK;
     if (m->n_events > ws_max_events()) { m->ws_state = -1; return CANOPY_OK; }
@@ -350,6 +368,14 @@ extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int variant = kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : kernel;
     if (variant == CANOPY_KERNEL_ROWS || variant == CANOPY_KERNEL_ROWS_LDS) return CANOPY_OK;
+    if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
+        canopy_status st = build_vs(ctx, m);
+        if (st != CANOPY_OK) return st;
+        if (m->vs_state == 1) return CANOPY_OK;
+        if (kernel == CANOPY_KERNEL_VALUE_SCATTER)
+            return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a value-scatter stream");
+        return CANOPY_OK; // AUTO: quantify falls back to ROWS
+    }
     if (variant != CANOPY_KERNEL_WAVE_STREAM) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
     canopy_status st = build_ws(ctx, m);
     if (st != CANOPY_OK) return st;
@@ -371,8 +397,18 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     int variant = params->kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : params->kernel;
-    if (variant != CANOPY_KERNEL_ROWS && variant != CANOPY_KERNEL_ROWS_LDS && variant != CANOPY_KERNEL_WAVE_STREAM)
+    if (variant != CANOPY_KERNEL_ROWS && variant != CANOPY_KERNEL_ROWS_LDS && variant != CANOPY_KERNEL_WAVE_STREAM &&
+        variant != CANOPY_KERNEL_VALUE_SCATTER)
         return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
+    if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
+        canopy_status pst = build_vs(ctx, const_cast<canopy_model*>(m)); // lazy, one-off, independent of p
+        if (pst != CANOPY_OK) return pst;
+        if (m->vs_state != 1) {
+            if (params->kernel == CANOPY_KERNEL_VALUE_SCATTER)
+                return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a value-scatter stream");
+            variant = CANOPY_KERNEL_ROWS;
+        }
+    }
     if (variant == CANOPY_KERNEL_ROWS_LDS && (size_t)m->n_events > rows_lds_table_limit_events())
         return fail(ctx, CANOPY_ERR_UNSUPPORTED, "logp table does not fit the LDS budget of ROWS_LDS");
     if (variant == CANOPY_KERNEL_WAVE_STREAM) {
@@ -404,6 +440,8 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     int grid;
     if (variant == CANOPY_KERNEL_WAVE_STREAM)
         grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : ws_default_grid(ctx->n_cu, m->n_ws);
+    else if (variant == CANOPY_KERNEL_VALUE_SCATTER)
+        grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : vs_default_grid(ctx->n_cu, m->n_slabs);
     else
         grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override
                                           : rows_kernel_default_grid(ctx->n_cu, variant, m->n_rows);
@@ -425,8 +463,15 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         ++ctx->timing_n;
     }
     int n_records = grid;
+    if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
+        if (want_mask) // slabs start at arbitrary rows: the kernel ORs partial words into a cleared mask
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
+    }
     HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
-    if (variant == CANOPY_KERNEL_WAVE_STREAM) {
+    if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
+        HIP_TRY(ctx, launch_vs_kernel(a, m->d_vs_stream, m->d_vs_off, m->d_vs_slab_row, m->vs_total_chunks, m->n_slabs,
+                                      grid, ctx->stream));
+    } else if (variant == CANOPY_KERNEL_WAVE_STREAM) {
         const int need_len = (params->limit_order != 0 && params->limit_order < m->max_row_len) ? 1 : 0;
         HIP_TRY(ctx, launch_ws_kernel(a, m->d_ws_stream, m->d_ws_off, m->ws_total_chunks, m->n_ws, need_len, grid,
                                       &n_records, ctx->stream));

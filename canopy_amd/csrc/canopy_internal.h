@@ -54,6 +54,12 @@ struct canopy_model {
     int64_t* d_ws_off = nullptr;
     int64_t ws_total_chunks = 0, n_ws = 0;
     int ws_state = 0; // 0 not built, 1 ready, -1 not representable (fall back to ROWS)
+    // derived value-scatter layout (kernels_vs.hip)
+    uint32_t* d_vs_stream = nullptr;
+    int64_t* d_vs_off = nullptr;
+    int64_t* d_vs_slab_row = nullptr;
+    int64_t vs_total_chunks = 0, n_slabs = 0;
+    int vs_state = 0;
 };
 
 namespace canopy {
@@ -100,5 +106,16 @@ hipError_t ws_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
 hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, const int64_t* ws_off,
                             int64_t total_chunks, int64_t n_ws, int need_len, int grid, int* n_records,
                             hipStream_t s);
+
+
+// kernels_vs.hip
+int vs_max_events();
+int vs_max_row_len();
+int vs_default_grid(int n_cu, int64_t n_slabs);
+hipError_t vs_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int64_t nnz, int32_t n_events,
+                    int32_t max_row_len, uint32_t** d_stream_out, int64_t** d_vs_off_out, int64_t** d_slab_row_out,
+                    int64_t* total_chunks_out, int64_t* n_slabs_out, bool* ok, hipStream_t s);
+hipError_t launch_vs_kernel(const RowKernelArgs& ra, const uint32_t* stream, const int64_t* vs_off,
+                            const int64_t* slab_row, int64_t total_chunks, int64_t n_slabs, int grid, hipStream_t s);
 
 } // namespace canopy

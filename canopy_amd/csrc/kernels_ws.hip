@@ -125,7 +125,7 @@ __device__ __noinline__ void ws_epilogue(double* sums, int64_t t, int lane, Acc*
     Acc acc = *acc_io;
     const int comp_base = it_begin * kWave;
     int n_comp = 0; // wave-uniform
-    constexpr int U = 4;
+    constexpr int U = 8;
     for (int i0 = it_begin; i0 < it_end; i0 += U) {
         double s[U];
 #pragma unroll
@@ -140,14 +140,16 @@ __device__ __noinline__ void ws_epilogue(double* sums, int64_t t, int lane, Acc*
             if (need_len && valid) len = (int)(row_ptr[r + 1] - row_ptr[r]);
             const bool keep = valid && (s[u] >= log_cut) && (limit_order == 0 || len <= limit_order);
             const unsigned long long m = __ballot(keep);
-            if (keep) {
-                acc.n_kept += 1.0;
-                if (s[u] > acc.max_logp) { acc.max_logp = s[u]; acc.argmax = (double)(row_offset + r); }
-                const int pos = comp_base + n_comp +
-                                (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                sums[pos] = s[u]; // pos <= this row's own slot, already read and cleared above
+            if (m != 0) { // wave-uniform: most 64-row groups have no survivor under the default cut-off
+                if (keep) {
+                    acc.n_kept += 1.0;
+                    if (s[u] > acc.max_logp) { acc.max_logp = s[u]; acc.argmax = (double)(row_offset + r); }
+                    const int pos = comp_base + n_comp +
+                                    (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    sums[pos] = s[u]; // pos <= this row's own slot, already read and cleared above
+                }
+                n_comp += __builtin_popcountll(m);
             }
-            n_comp += __builtin_popcountll(m);
             if (row_logp_out != nullptr && valid) row_logp_out[r] = s[u];
             if (keep_mask_out != nullptr && lane == 0 && r < n_rows) keep_mask_out[r >> 6] = m;
         }
@@ -400,7 +402,9 @@ hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, con
         case 2: return launch_ws_t<4096, 8, 2>(ra, stream, ws_off, sc, grid, s); // no LDS adds
         case 4: return launch_ws_t<4096, 8, 4>(ra, stream, ws_off, sc, grid, s); // no epilogue
         case 7: return launch_ws_t<4096, 8, 7>(ra, stream, ws_off, sc, grid, s); // stream loads only
-        case 16: return launch_ws_t<4096, 16, 0>(ra, stream, ws_off, sc, grid, s);
+        case 10: return launch_ws_t<4096, 10, 0>(ra, stream, ws_off, sc, grid, s);
+        case 12: return launch_ws_t<4096, 12, 0>(ra, stream, ws_off, sc, grid, s);
+        case 6: return launch_ws_t<4096, 6, 0>(ra, stream, ws_off, sc, grid, s);
         default: return launch_ws_t<4096, 8, 0>(ra, stream, ws_off, sc, grid, s);
     }
 }

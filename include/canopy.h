@@ -187,8 +187,10 @@ enum {
     CANOPY_KERNEL_AUTO = 0,
     CANOPY_KERNEL_ROWS = 1,     /* lane-per-row, LDS-staged col_idx slab, logp gathered via L2 */
     CANOPY_KERNEL_ROWS_LDS = 2, /* same, logp table resident in LDS (needs E*8 B <= table budget) */
-    CANOPY_KERNEL_WAVE_STREAM = 3 /* derived layout: per-wave column-ordered entry stream, row sums in
-                                     LDS (large E); built once by canopy_model_prepare */
+    CANOPY_KERNEL_WAVE_STREAM = 3, /* derived layout: per-wave column-ordered entry stream, row sums in
+                                      LDS (large E); built once by canopy_model_prepare */
+    CANOPY_KERNEL_VALUE_SCATTER = 4 /* derived layout: per-slab column-ordered entry stream, gathered
+                                       values scattered to CSR slots in LDS, lane-per-row sums (large E) */
 };
 
 CANOPY_API void canopy_quant_params_default(canopy_quant_params* params);

@@ -25,13 +25,15 @@ def rel(a, b):
     return abs(a - b) / max(abs(b), 1e-300)
 
 
-def variants(n_events):
+def variants(n_events, max_row_len=10):
     from canopy_amd import _capi
     v = [_capi.KERNEL_ROWS]
     if n_events <= 12288:
         v.append(_capi.KERNEL_ROWS_LDS)
     if n_events <= (1 << 19):
         v.append(_capi.KERNEL_WAVE_STREAM)
+    if n_events <= (1 << 18) and max_row_len <= 4095:
+        v.append(_capi.KERNEL_VALUE_SCATTER)
     return v
 
 
@@ -41,7 +43,8 @@ def check_against_oracle(ctx, oracle, row_ptr, col, p, n_events, cut_off, limit_
                            row_offset=row_offset)
     model = ctx.upload(row_ptr, col, n_events, row_offset=row_offset)
     model.set_probabilities(p)
-    for kern in variants(n_events):
+    max_len = int(np.diff(row_ptr).max()) if len(row_ptr) > 1 else 0
+    for kern in variants(n_events, max_len):
         prm = default_params(cut_off=cut_off, limit_order=limit_order,
                              flags=_capi.QUANT_ROW_LOGP | _capi.QUANT_KEEP_MASK, kernel=kern)
         got = ctx.quantify(model, prm)
