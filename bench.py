@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, else a CANOPY_KERNEL_* id")
     ap.add_argument("--cpu-sample-rows", type=int, default=20_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearse the N>1 code path (process group, gather buffer, all-reduce) at world size 1")
     args = ap.parse_args()
 
     import torch  # first: one HIP runtime shared in-process
@@ -84,12 +86,18 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the quantification path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
-    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
-    ctx = canopy_amd.Context(device=local_rank, stream=stream)
+    # One stream carries the kernels AND the collective: a dedicated (non-default) torch stream whose
+    # raw hipStream_t is handed to the library (a NULL handle would make the library create its own).
+    tstream = torch.cuda.Stream(device=local_rank) if use_dist else None
+    ctx = canopy_amd.Context(device=local_rank, stream=tstream.cuda_stream if tstream is not None else None)
     p = canopy_amd.synthetic_probabilities(SEED, args.events)
     t0 = time.time()
     model = ctx.synthetic(SEED, args.rows_per_gpu, args.events, args.avg_nnz, first_row=rank * args.rows_per_gpu)
@@ -102,17 +110,18 @@ def main():
     ctx.synchronize()
     t_prepare = time.time() - t0
     info = model.info()
-    comb = ShardCombiner(ctx=ctx) if world > 1 else None
+    comb = ShardCombiner(ctx=ctx) if use_dist else None
 
     def step():
         ctx.quantify_async(model, prm)
         if comb is not None:
-            comb.all_reduce()  # K5: the one collective, on the same stream as the kernels
+            with torch.cuda.stream(tstream):
+                comb.all_reduce(force=args.force_dist)  # K5: the one collective, same stream as the kernels
 
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -126,7 +135,7 @@ def main():
     ctx.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -135,7 +144,8 @@ def main():
     k_ms_sum, tot_ms_sum, n_timed = ctx.timing_end()
 
     if comb is not None:
-        result = comb.result()
+        with torch.cuda.stream(tstream):
+            result = comb.result()
     else:
         result = canopy_amd.combine_partials([ctx.fetch_partial()])
 
@@ -183,7 +193,7 @@ def main():
     if comb is not None:
         comb.detach()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -508,7 +508,7 @@ canopy_status canopy_combine_partials(const canopy_partial* parts, int32_t n, ui
         rare.add(parts[k].rare_hi); rare.add(parts[k].rare_lo);
         l1p.add(parts[k].log1p_hi); l1p.add(parts[k].log1p_lo);
         n_kept += parts[k].n_kept; n_certain += parts[k].n_certain;
-        if (parts[k].argmax_row >= 0.0 &&
+        if (parts[k].n_kept > 0.0 && parts[k].argmax_row >= 0.0 && // a record without kept rows has no argmax
             (parts[k].max_logp > max_logp ||
              (parts[k].max_logp == max_logp && (argmax < 0.0 || parts[k].argmax_row < argmax)))) {
             max_logp = parts[k].max_logp; argmax = parts[k].argmax_row;

@@ -47,12 +47,16 @@ class ShardCombiner:
         n = capi.PARTIAL_DOUBLES
         self.buf[self.rank * n:(self.rank + 1) * n] = torch.from_numpy(rec).to(self.buf.device)
 
-    def all_reduce(self):
-        """The single collective of the path. Enqueued on the current stream for RCCL."""
-        if self.world > 1:
+    def all_reduce(self, force=False):
+        """The single collective of the path. Enqueued on the current torch stream for RCCL: the
+        caller makes the context's stream current (`with torch.cuda.stream(s)`), so the collective is
+        ordered after the final-reduce kernel that fills this rank's slot."""
+        if self.world > 1 or (force and dist.is_initialized()):
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
 
     def partials(self):
+        if self.ctx is not None:
+            self.ctx.synchronize()
         host = self.buf.detach().to("cpu").numpy()
         n = capi.PARTIAL_DOUBLES
         return [capi.Partial(*host[k * n:(k + 1) * n].tolist()) for k in range(self.world)]

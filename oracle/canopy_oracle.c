@@ -250,7 +250,7 @@ void oracle_combine(const oracle_result* parts, int32_t n, oracle_result* out) {
         csum_add(&rare, parts[k].rare_hi); csum_add(&rare, parts[k].rare_lo);
         csum_add(&l1p, parts[k].log1p_hi); csum_add(&l1p, parts[k].log1p_lo);
         n_kept += parts[k].n_kept; n_certain += parts[k].n_certain;
-        if (parts[k].argmax_row >= 0.0 &&
+        if (parts[k].n_kept > 0.0 && parts[k].argmax_row >= 0.0 &&
             (parts[k].max_logp > max_logp ||
              (parts[k].max_logp == max_logp && (argmax < 0.0 || parts[k].argmax_row < argmax)))) {
             max_logp = parts[k].max_logp; argmax = parts[k].argmax_row;

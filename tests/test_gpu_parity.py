@@ -225,3 +225,29 @@ def test_config3_full_size_properties(gpu_ctx, oracle):
     assert both.max_logp == whole.max_logp
     assert rel(both.rare_event, whole.rare_event) < TOL and rel(both.mcub, whole.mcub) < TOL
     assert part_whole.n_kept == whole.n_kept
+
+
+def test_gather_slot_buffer_single_rank(gpu_ctx, oracle):
+    """K5 plumbing on the GPU: the final-reduce kernel writes this rank's record into its slot of the
+    all-reduce buffer and zeroes the others (here world=3, rank=1 emulated without a process group)."""
+    import torch
+    from canopy_amd import _capi, combine_partials, default_params
+    row_ptr, col = oracle.synth_csr(SEED, 30000, 1000, 4)
+    p = oracle.synth_probabilities(SEED, 1000)
+    model = gpu_ctx.upload(row_ptr, col, 1000, row_offset=777)
+    model.set_probabilities(p)
+    buf = torch.full((3 * _capi.PARTIAL_DOUBLES,), 7.0, dtype=torch.float64, device="cuda")
+    _capi.check(_capi.lib().canopy_ctx_set_gather_buffer(gpu_ctx.handle, buf.data_ptr(), 3, 1), "set_gather")
+    try:
+        want = gpu_ctx.quantify(model, default_params(cut_off=1e-9))
+        gpu_ctx.synchronize()
+        host = buf.cpu().numpy()
+    finally:
+        _capi.lib().canopy_ctx_set_gather_buffer(gpu_ctx.handle, None, 0, 0)
+    assert np.all(host[:8] == 0.0) and np.all(host[16:] == 0.0)
+    got = combine_partials([_capi.Partial(*host[k * 8:(k + 1) * 8].tolist()) for k in range(3)])
+    assert (got.rare_event, got.mcub, got.n_kept, got.argmax_row) == (want.rare_event, want.mcub, want.n_kept,
+                                                                     want.argmax_row)
+    o = oracle.quantify(row_ptr, col, p, cut_off=1e-9, row_offset=777)
+    assert got.n_kept == int(o.n_kept) and got.argmax_row == int(o.argmax_row)
+    model.close()
