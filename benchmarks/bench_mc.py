@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Monte-Carlo throughput (BASELINE config 5: 1e9 Bernoulli samples through an AND/OR gate DAG,
+bit-packed u64). Prints one JSON line: samples/s, event-draws/s, gate-evals/s. Compute/RNG bound: the
+roofline that applies is the vector-ALU rate, not HBM. Multi-GPU: the sample range shards across
+ranks (first_sample), hits add up exactly; run under torch.distributed.run for N>1."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--samples", type=int, default=1_000_000_000)
+    ap.add_argument("--events", type=int, default=100)
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--width", type=int, default=250)
+    ap.add_argument("--fan-in", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=3)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import canopy_amd
+    from canopy_amd.quantifier import Dag
+    from canopy_amd.synthetic import layered_dag
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = canopy_amd.Context(device=local_rank)
+    dag = layered_dag(20250704, args.events, args.layers, args.width, args.fan_in, atleast_every=5)
+    p = np.random.default_rng(20250704).uniform(0.002, 0.1, args.events)
+    d = Dag(ctx, dag)
+    d.set_probabilities(p)
+    per_rank = (args.samples // world) // 64 * 64
+    d.run(20250704, per_rank, first_sample=rank * per_rank)  # warm-up
+    t0 = time.perf_counter()
+    ms = 0.0
+    for _ in range(args.steps):
+        r = d.run(20250704, per_rank, first_sample=rank * per_rank)
+        ms += r.elapsed_kernel_ms
+    elapsed = time.perf_counter() - t0
+    hits = torch.tensor([r.hits], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(hits)  # the single exchange: one u64 sum
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        n_gates = len(dag["gate_type"]); total = per_rank * world
+        print(json.dumps({"metric": "Monte-Carlo samples/sec", "value": total * args.steps / elapsed, "unit": "samples/s",
+                          "n_gpus": world, "steps": args.steps, "ms_per_step": elapsed * 1e3 / args.steps,
+                          "kernel_ms": ms / args.steps, "dtype": "u64 bit-packed", "data": "synthetic",
+                          "config": {"workload": "layered AND/OR/K-of-N DAG", "samples": total, "n_events": args.events,
+                                     "n_gates": n_gates, "fan_in": args.fan_in, "layers": args.layers},
+                          "event_draws_per_s": total * args.events * args.steps / elapsed,
+                          "gate_evals_per_s": total * n_gates * args.steps / elapsed,
+                          "estimate": int(hits.item()) / total, "hits": int(hits.item())}))
+    d.close(); ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,7 @@ UPLOAD_DEVICE_POINTERS = 2
 
 APPROX_RARE_EVENT, APPROX_MCUB, APPROX_BOTH = 1, 2, 3
 QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK = 1, 2, 4
+GATE_AND, GATE_OR, GATE_ATLEAST, GATE_XOR, GATE_NOT, GATE_NAND, GATE_NOR, GATE_NULL = range(8)
 KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER = 0, 1, 2, 3, 4
 
 
@@ -54,6 +55,20 @@ class Partial(C.Structure):
     _fields_ = [("rare_hi", C.c_double), ("rare_lo", C.c_double), ("log1p_hi", C.c_double),
                 ("log1p_lo", C.c_double), ("n_kept", C.c_double), ("n_certain", C.c_double),
                 ("max_logp", C.c_double), ("argmax_row", C.c_double)]
+
+
+class DagView(C.Structure):
+    _fields_ = [("n_events", C.c_int32), ("n_gates", C.c_int32), ("gate_type", C.c_void_p), ("gate_min", C.c_void_p),
+                ("arg_ptr", C.c_void_p), ("args", C.c_void_p), ("top", C.c_int32), ("reserved", C.c_int32)]
+
+
+class McParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_sample", C.c_int64), ("num_trials", C.c_int64)]
+
+
+class McResult(C.Structure):
+    _fields_ = [("hits", C.c_int64), ("num_trials", C.c_int64), ("estimate", C.c_double), ("std_error", C.c_double),
+                ("elapsed_kernel_ms", C.c_double)]
 
 
 class QuantResult(C.Structure):
@@ -86,6 +101,12 @@ SIGNATURES = {
     "canopy_combine_partials": (C.c_int, [C.POINTER(Partial), C.c_int32, C.c_uint32, C.POINTER(QuantResult)]),
     "canopy_fetch_row_logp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "canopy_fetch_keep_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "canopy_dag_upload": (C.c_int, [C.c_void_p, C.POINTER(DagView), C.POINTER(C.c_void_p)]),
+    "canopy_dag_free": (None, [C.c_void_p]),
+    "canopy_dag_set_probabilities": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "canopy_mc_run_async": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(McParams)]),
+    "canopy_mc_fetch": (C.c_int, [C.c_void_p, C.POINTER(McResult)]),
+    "canopy_mc_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(McParams), C.POINTER(McResult)]),
     "canopy_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "canopy_timing_begin": (C.c_int, [C.c_void_p, C.c_int32]),
     "canopy_timing_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),

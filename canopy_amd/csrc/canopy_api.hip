@@ -152,6 +152,9 @@ void canopy_ctx_free(canopy_ctx* ctx) {
     if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
     if (ctx->d_row_logp) (void)hipFree(ctx->d_row_logp);
     if (ctx->d_keep_mask) (void)hipFree(ctx->d_keep_mask);
+    if (ctx->d_mc_hits) (void)hipFree(ctx->d_mc_hits);
+    if (ctx->h_mc_hits) (void)hipHostFree(ctx->h_mc_hits);
+    for (auto ev : ctx->ev_mc) if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -37,7 +37,26 @@ struct canopy_ctx {
     int timing_max = 0, timing_n = 0;
     bool timing_on = false;
 
+    // K6 Monte-Carlo
+    unsigned long long* d_mc_hits = nullptr; // [1]
+    unsigned long long* h_mc_hits = nullptr; // pinned
+    int64_t mc_last_trials = 0;
+    hipEvent_t ev_mc[2] = {nullptr, nullptr};
+
     std::string last_error;
+};
+
+struct canopy_dag {
+    int device = 0;
+    int32_t n_events = 0, n_gates = 0, n_levels = 0, top = 0;
+    int32_t* d_gate_type = nullptr;  // level-ordered
+    int32_t* d_gate_min = nullptr;
+    int32_t* d_gate_node = nullptr;  // output node id of the k-th level-ordered gate
+    int32_t* d_arg_ptr = nullptr;    // [n_gates+1], level-ordered
+    int32_t* d_args = nullptr;
+    int32_t* d_level_ptr = nullptr;  // [n_levels+1] into the level-ordered gate list
+    uint64_t* d_thresh = nullptr;    // [n_events] ceil(p * 2^53)
+    bool has_p = false;
 };
 
 struct canopy_model {

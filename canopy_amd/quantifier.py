@@ -130,6 +130,53 @@ class Context:
         return out
 
 
+class Dag:
+    """A gate DAG resident on the device (canopy_dag) for the Monte-Carlo path (K6)."""
+
+    def __init__(self, ctx, dag):
+        self._ctx = ctx
+        self._keep = [_as(dag["gate_type"], np.int32), _as(dag["gate_min"], np.int32), _as(dag["arg_ptr"], np.int32),
+                      _as(dag["args"], np.int32)]
+        gt, gm, ap, ar = self._keep
+        view = capi.DagView(n_events=dag["n_events"], n_gates=len(gt), gate_type=gt.ctypes.data, gate_min=gm.ctypes.data,
+                            arg_ptr=ap.ctypes.data, args=ar.ctypes.data if ar.size else None, top=dag["top"], reserved=0)
+        self._h = C.c_void_p()
+        capi.check(capi.lib().canopy_dag_upload(ctx.handle, C.byref(view), C.byref(self._h)), "canopy_dag_upload", ctx.handle)
+        self.n_events = dag["n_events"]
+
+    def close(self):
+        if self._h:
+            capi.lib().canopy_dag_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_probabilities(self, p):
+        p = _as(p, np.float64)
+        if p.shape != (self.n_events,):
+            raise ValueError("p must have n_events entries")
+        capi.check(capi.lib().canopy_dag_set_probabilities(self._ctx.handle, self._h, p.ctypes.data),
+                   "canopy_dag_set_probabilities", self._ctx.handle)
+
+    def run_async(self, seed, num_trials, first_sample=0):
+        prm = capi.McParams(seed=seed, first_sample=first_sample, num_trials=num_trials)
+        capi.check(capi.lib().canopy_mc_run_async(self._ctx.handle, self._h, C.byref(prm)), "canopy_mc_run_async",
+                   self._ctx.handle)
+
+    def fetch(self):
+        res = capi.McResult()
+        capi.check(capi.lib().canopy_mc_fetch(self._ctx.handle, C.byref(res)), "canopy_mc_fetch", self._ctx.handle)
+        return res
+
+    def run(self, seed, num_trials, first_sample=0):
+        self.run_async(seed, num_trials, first_sample)
+        return self.fetch()
+
+
 class Model:
     """A CSR cut-set shard resident in HBM (canopy_model)."""
 

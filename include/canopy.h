@@ -265,6 +265,66 @@ CANOPY_API canopy_status canopy_fetch_keep_mask(canopy_ctx* ctx, const canopy_mo
 CANOPY_API canopy_status canopy_last_kernel_ms(canopy_ctx* ctx, double* row_kernel_ms,
                                                double* total_ms);
 
+/* ---- K6: direct Monte-Carlo propagation through the gate DAG ------------------------------------ */
+/*
+ * Reference vocabulary: Approximation::kMonteCarlo (src/mef/openpsa/settings.h:19), num_trials and
+ * seed (settings.h:324-325), gates = Formula{connective, min, args} with complemented arguments
+ * (src/mef/openpsa/event/formula.h:6-148), connective order of event.h:143-157. The reference has
+ * no simulator; semantics here (oracle/canopy_oracle.c restates them bit for bit):
+ *   sample n of basic event j is TRUE iff (mix64(ek_j + n) >> 11) < ceil(p_j * 2^53), a counter-based
+ *   draw (ek_j derived from seed and j), so any sample range gives the same bits on any device;
+ *   64 samples are packed into one u64 word per node; gates are evaluated with bitwise logic
+ *   (ATLEAST through a bit-sliced adder); hits = popcount of the top node's words.
+ * Integer result: bit-exact against the oracle.
+ */
+typedef enum canopy_connective { /* same order as the reference's Connective enum */
+    CANOPY_GATE_AND = 0,
+    CANOPY_GATE_OR = 1,
+    CANOPY_GATE_ATLEAST = 2, /* K-of-N, K in gate_min */
+    CANOPY_GATE_XOR = 3,
+    CANOPY_GATE_NOT = 4,
+    CANOPY_GATE_NAND = 5,
+    CANOPY_GATE_NOR = 6,
+    CANOPY_GATE_NULL = 7     /* single-argument pass-through */
+} canopy_connective;
+
+typedef struct canopy_dag_view {
+    int32_t n_events;
+    int32_t n_gates;
+    const int32_t* gate_type; /* [n_gates] canopy_connective */
+    const int32_t* gate_min;  /* [n_gates] K of ATLEAST gates (ignored otherwise); NULL if there are none */
+    const int32_t* arg_ptr;   /* [n_gates+1] */
+    const int32_t* args;      /* node ids: j < n_events is basic event j, n_events + g is gate g (g smaller
+                                 than the gate that uses it: topological order); ~id = complemented argument */
+    int32_t top;              /* node id whose probability is estimated */
+    int32_t reserved;
+} canopy_dag_view;
+
+typedef struct canopy_dag canopy_dag;
+
+CANOPY_API canopy_status canopy_dag_upload(canopy_ctx* ctx, const canopy_dag_view* dag, canopy_dag** out);
+CANOPY_API void canopy_dag_free(canopy_dag* dag);
+CANOPY_API canopy_status canopy_dag_set_probabilities(canopy_ctx* ctx, canopy_dag* dag, const double* p);
+
+typedef struct canopy_mc_params {
+    uint64_t seed;        /* settings.h:324 */
+    int64_t first_sample; /* global index of this shard's first sample, a multiple of 64 */
+    int64_t num_trials;   /* settings.h:325; samples drawn by THIS call */
+} canopy_mc_params;
+
+typedef struct canopy_mc_result {
+    int64_t hits;
+    int64_t num_trials;
+    double estimate;   /* hits / num_trials */
+    double std_error;  /* sqrt(estimate * (1 - estimate) / num_trials) */
+    double elapsed_kernel_ms;
+} canopy_mc_result;
+
+CANOPY_API canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* dag, const canopy_mc_params* params);
+CANOPY_API canopy_status canopy_mc_fetch(canopy_ctx* ctx, canopy_mc_result* result);
+CANOPY_API canopy_status canopy_mc_run(canopy_ctx* ctx, const canopy_dag* dag, const canopy_mc_params* params,
+                                       canopy_mc_result* result);
+
 /* ---- per-launch timing over a region (HIP events on the context's stream) -------------------- */
 /*
  * Between begin and end every canopy_quantify_async records an event triple around its row

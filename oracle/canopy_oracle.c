@@ -276,3 +276,78 @@ int oracle_quantify_product_domain(int64_t n_rows, const int64_t* row_ptr, const
     *one_minus_prod = (double)(1.0L - prod);
     return 0;
 }
+
+/* ---- K6: Monte-Carlo through the gate DAG ------------------------------------------------------- */
+
+typedef struct mc_job {
+    int32_t n_events, n_gates; const int32_t *gate_type, *gate_min, *arg_ptr, *args; int32_t top;
+    const uint64_t* thresh; uint64_t key; int64_t first_word, w0, w1, num_trials; int64_t hits;
+} mc_job;
+
+static inline uint64_t mc_node(const uint64_t* node, int32_t a) { return a >= 0 ? node[a] : ~node[~a]; }
+
+static void* mc_worker(void* arg) {
+    mc_job* j = (mc_job*)arg;
+    uint64_t* node = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(j->n_events + j->n_gates + 1));
+    int64_t hits = 0;
+    for (int64_t w = j->w0; w < j->w1; ++w) {
+        for (int32_t ev = 0; ev < j->n_events; ++ev) {
+            uint64_t ek = mix64(j->key ^ (uint64_t)ev), word = 0;
+            for (int l = 0; l < 64; ++l) {
+                uint64_t n = (uint64_t)(j->first_word + w) * 64u + (uint64_t)l;
+                if ((mix64(ek + n) >> 11) < j->thresh[ev]) word |= (uint64_t)1 << l;
+            }
+            node[ev] = word;
+        }
+        for (int32_t g = 0; g < j->n_gates; ++g) {
+            int32_t b = j->arg_ptr[g], e = j->arg_ptr[g + 1], type = j->gate_type[g];
+            uint64_t r = 0;
+            if (type == 0 || type == 5) { r = ~(uint64_t)0; for (int32_t k = b; k < e; ++k) r &= mc_node(node, j->args[k]); if (type == 5) r = ~r; }
+            else if (type == 1 || type == 6) { for (int32_t k = b; k < e; ++k) r |= mc_node(node, j->args[k]); if (type == 6) r = ~r; }
+            else if (type == 3) { for (int32_t k = b; k < e; ++k) r ^= mc_node(node, j->args[k]); }
+            else if (type == 4) r = ~mc_node(node, j->args[b]);
+            else if (type == 7) r = mc_node(node, j->args[b]);
+            else { /* ATLEAST: per sample, count TRUE arguments and compare with K (plain counting) */
+                for (int l = 0; l < 64; ++l) {
+                    int cnt = 0;
+                    for (int32_t k = b; k < e; ++k) cnt += (int)((mc_node(node, j->args[k]) >> l) & 1u);
+                    if (cnt >= j->gate_min[g]) r |= (uint64_t)1 << l;
+                }
+            }
+            node[j->n_events + g] = r;
+        }
+        int64_t left = j->num_trials - w * 64;
+        uint64_t valid = left >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << left) - 1);
+        hits += __builtin_popcountll(node[j->top] & valid);
+    }
+    free(node);
+    j->hits = hits;
+    return NULL;
+}
+
+int64_t oracle_mc(int32_t n_events, int32_t n_gates, const int32_t* gate_type, const int32_t* gate_min,
+                  const int32_t* arg_ptr, const int32_t* args, int32_t top, const double* p, uint64_t seed,
+                  int64_t first_sample, int64_t num_trials, int32_t n_threads) {
+    if (n_events < 0 || n_gates < 0 || num_trials < 0 || first_sample < 0 || (first_sample & 63)) return -1;
+    uint64_t* thresh = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n_events + 1));
+    for (int32_t j = 0; j < n_events; ++j) {
+        if (!(p[j] >= 0.0 && p[j] <= 1.0)) { free(thresh); return -1; }
+        thresh[j] = (uint64_t)ceil(p[j] * 9007199254740992.0);
+    }
+    uint64_t key = mix64(seed ^ ((uint64_t)4 * 0xD1B54A32D192ED03ULL));
+    int64_t n_words = (num_trials + 63) / 64;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    pthread_t th[256];
+    mc_job jobs[256];
+    for (int32_t t = 0; t < n_threads; ++t) {
+        jobs[t] = (mc_job){n_events, n_gates, gate_type, gate_min, arg_ptr, args, top, thresh, key,
+                           first_sample / 64, n_words * t / n_threads, n_words * (t + 1) / n_threads, num_trials, 0};
+        if (t + 1 < n_threads) pthread_create(&th[t], NULL, mc_worker, &jobs[t]);
+    }
+    mc_worker(&jobs[n_threads - 1]);
+    int64_t hits = jobs[n_threads - 1].hits;
+    for (int32_t t = 0; t + 1 < n_threads; ++t) { pthread_join(th[t], NULL); hits += jobs[t].hits; }
+    free(thresh);
+    return hits;
+}

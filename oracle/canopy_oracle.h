@@ -68,6 +68,16 @@ int oracle_synth_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int32_t n
 /* p_j = 10^(-8 + 5 u_j), u_j uniform [0,1): log-uniform on [1e-8, 1e-3). */
 void oracle_synth_probabilities(uint64_t seed, int32_t n_events, double* p);
 
+/*
+ * K6 restatement: direct Monte-Carlo through the gate DAG (include/canopy.h, canopy_dag_view). Same
+ * counter-based draw as the device: sample n of event j is TRUE iff
+ * (mix64(mix64(key ^ j) + n) >> 11) < ceil(p_j * 2^53), key = stream key of (seed, stream 4).
+ * Gates in the caller's (topological) order, one u64 word of 64 samples per node. Returns hits, or -1.
+ */
+int64_t oracle_mc(int32_t n_events, int32_t n_gates, const int32_t* gate_type, const int32_t* gate_min,
+                  const int32_t* arg_ptr, const int32_t* args, int32_t top, const double* p, uint64_t seed,
+                  int64_t first_sample, int64_t num_trials, int32_t n_threads);
+
 /* nnz-balanced contiguous shard bounds (mirror of canopy_shard_rows). */
 void oracle_shard_rows(const int64_t* row_ptr, int64_t n_rows, int32_t n_shards, int64_t* bounds);
 

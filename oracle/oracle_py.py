@@ -52,6 +52,9 @@ def lib():
         l.oracle_synth_probabilities.argtypes = [C.c_uint64, C.c_int32, C.c_void_p]
         l.oracle_shard_rows.restype = None
         l.oracle_shard_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        l.oracle_mc.restype = C.c_int64
+        l.oracle_mc.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                C.c_uint64, C.c_int64, C.c_int64, C.c_int32]
         _lib = l
     return _lib
 
@@ -121,3 +124,17 @@ def shard_rows(row_ptr, n_shards):
     b = np.empty(n_shards + 1, dtype=np.int64)
     lib().oracle_shard_rows(row_ptr.ctypes.data, len(row_ptr) - 1, n_shards, b.ctypes.data)
     return b
+
+
+def mc(dag, p, seed, num_trials, first_sample=0, n_threads=1):
+    """dag: dict with n_events, gate_type, gate_min, arg_ptr, args, top (canopy_dag_view fields)."""
+    gt = np.ascontiguousarray(dag["gate_type"], dtype=np.int32)
+    gm = np.ascontiguousarray(dag["gate_min"], dtype=np.int32)
+    ap = np.ascontiguousarray(dag["arg_ptr"], dtype=np.int32)
+    ar = np.ascontiguousarray(dag["args"], dtype=np.int32)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    hits = lib().oracle_mc(dag["n_events"], len(gt), gt.ctypes.data, gm.ctypes.data, ap.ctypes.data, ar.ctypes.data,
+                           dag["top"], p.ctypes.data, seed, first_sample, num_trials, n_threads)
+    if hits < 0:
+        raise ValueError("oracle_mc: invalid input")
+    return int(hits)
