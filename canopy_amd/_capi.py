@@ -71,6 +71,11 @@ class McResult(C.Structure):
                 ("elapsed_kernel_ms", C.c_double)]
 
 
+class FtInfo(C.Structure):
+    _fields_ = [("n_basic_events", C.c_int32), ("n_gates", C.c_int32), ("n_house_events", C.c_int32),
+                ("top_gate", C.c_int32), ("n_dag_args", C.c_int32), ("reserved", C.c_int32)]
+
+
 class QuantResult(C.Structure):
     _fields_ = [("rare_event", C.c_double), ("mcub", C.c_double), ("n_kept", C.c_int64),
                 ("argmax_row", C.c_int64), ("max_logp", C.c_double), ("elapsed_kernel_ms", C.c_double)]
@@ -107,6 +112,16 @@ SIGNATURES = {
     "canopy_mc_run_async": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(McParams)]),
     "canopy_mc_fetch": (C.c_int, [C.c_void_p, C.POINTER(McResult)]),
     "canopy_mc_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(McParams), C.POINTER(McResult)]),
+    "canopy_ft_parse": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "canopy_ft_parse_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "canopy_ft_free": (None, [C.c_void_p]),
+    "canopy_ft_get_info": (C.c_int, [C.c_void_p, C.POINTER(FtInfo)]),
+    "canopy_ft_basic_event_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
+    "canopy_ft_gate_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
+    "canopy_ft_probabilities": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "canopy_ft_dag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "canopy_ft_cut_sets": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
+                                     C.c_void_p]),
     "canopy_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "canopy_timing_begin": (C.c_int, [C.c_void_p, C.c_int32]),
     "canopy_timing_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),

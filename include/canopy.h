@@ -325,6 +325,49 @@ CANOPY_API canopy_status canopy_mc_fetch(canopy_ctx* ctx, canopy_mc_result* resu
 CANOPY_API canopy_status canopy_mc_run(canopy_ctx* ctx, const canopy_dag* dag, const canopy_mc_params* params,
                                        canopy_mc_result* result);
 
+/* ---- K0: fault tree -> cut sets / gate DAG (host only, no device needed) --------------------------- */
+/*
+ * A small reader for the Open-PSA Model Exchange Format subset that fault trees need
+ * (<define-fault-tree>, <define-gate> with and / or / atleast min=K / not / xor / nand / nor / a bare
+ * event reference, <define-basic-event> with <float value=.../>, <define-house-event> with
+ * <constant value="true|false"/>, <model-data>), and the lowering the kernels consume. It stands in for
+ * the reference's src/io/xml + src/mef/openpsa Initializer on this path (they do not build in this
+ * toolchain) and is restated from the format, not from their text:
+ *   - house events are folded as Boolean constants (reference event.h:34-57),
+ *   - the top event is the gate no other gate refers to (reference fault_tree.h:151-186),
+ *   - p[j] = the basic event's constant expression (reference event.h:93-96, expr/constant.h:23-31).
+ * canopy_ft_cut_sets: MOCUS-style top-down expansion with minimisation (coherent trees: and / or /
+ * atleast; a tree with negation returns CANOPY_ERR_UNSUPPORTED and must use the Monte-Carlo DAG),
+ * rows = minimal cut sets with ascending basic-event indices = the CSR of canopy_model_upload.
+ */
+typedef struct canopy_ft canopy_ft;
+
+typedef struct canopy_ft_info {
+    int32_t n_basic_events;
+    int32_t n_gates;
+    int32_t n_house_events;
+    int32_t top_gate;   /* index into the gate list */
+    int32_t n_dag_args; /* total arguments of the folded gate DAG (size of `args` in canopy_ft_dag) */
+    int32_t reserved;
+} canopy_ft_info;
+
+/* err (may be NULL) receives a NUL-terminated message on failure. */
+CANOPY_API canopy_status canopy_ft_parse(const char* xml_text, size_t len, canopy_ft** out, char* err, size_t err_len);
+CANOPY_API canopy_status canopy_ft_parse_file(const char* path, canopy_ft** out, char* err, size_t err_len);
+CANOPY_API void canopy_ft_free(canopy_ft* ft);
+CANOPY_API canopy_status canopy_ft_get_info(const canopy_ft* ft, canopy_ft_info* info);
+CANOPY_API const char* canopy_ft_basic_event_name(const canopy_ft* ft, int32_t j);
+CANOPY_API const char* canopy_ft_gate_name(const canopy_ft* ft, int32_t g);
+CANOPY_API canopy_status canopy_ft_probabilities(const canopy_ft* ft, double* p /* [n_basic_events] */);
+/* Gate DAG in canopy_dag_view layout (house events folded, gates in topological order); arrays sized
+   from canopy_ft_info: gate_type/gate_min [n_gates], arg_ptr [n_gates+1], args [n_dag_args]. */
+CANOPY_API canopy_status canopy_ft_dag(const canopy_ft* ft, int32_t* gate_type, int32_t* gate_min, int32_t* arg_ptr,
+                                       int32_t* args, int32_t* top);
+/* Minimal cut sets up to limit_order (0 = no limit). First call with row_ptr = col_idx = NULL to get the
+   sizes, then with arrays of n_sets+1 and nnz entries. */
+CANOPY_API canopy_status canopy_ft_cut_sets(const canopy_ft* ft, int32_t limit_order, int64_t* n_sets, int64_t* nnz,
+                                            int64_t* row_ptr, int32_t* col_idx);
+
 /* ---- per-launch timing over a region (HIP events on the context's stream) -------------------- */
 /*
  * Between begin and end every canopy_quantify_async records an event triple around its row

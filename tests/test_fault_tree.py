@@ -1,0 +1,188 @@
+"""K0 -- Open-PSA MEF fault tree -> cut sets / gate DAG (config 1 plumbing, host logic).
+The reference has no example model and no lowering, so the answers are pinned by brute force: the
+minimal cut sets of a coherent tree are the minimal TRUE assignments of its truth table."""
+import itertools
+import math
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXAMPLE = os.path.join(ROOT, "examples", "two_of_three_plus_or.xml")
+
+
+def eval_dag(dag, bits):
+    from canopy_amd import _capi as c
+    val = list(bits)
+    for g, t in enumerate(dag["gate_type"]):
+        a = [val[x] if x >= 0 else 1 - val[~x] for x in dag["args"][dag["arg_ptr"][g]:dag["arg_ptr"][g + 1]]]
+        if t == c.GATE_AND: r = int(all(a))
+        elif t == c.GATE_OR: r = int(any(a))
+        elif t == c.GATE_ATLEAST: r = int(sum(a) >= dag["gate_min"][g])
+        elif t == c.GATE_XOR: r = sum(a) % 2
+        elif t == c.GATE_NOT: r = 1 - a[0]
+        elif t == c.GATE_NAND: r = 1 - int(all(a))
+        elif t == c.GATE_NOR: r = 1 - int(any(a))
+        else: r = a[0]
+        val.append(r)
+    return val[dag["top"]]
+
+
+def brute_force(dag, p):
+    n = dag["n_events"]
+    true_sets, prob = [], 0.0
+    for bits in itertools.product((0, 1), repeat=n):
+        if eval_dag(dag, bits):
+            true_sets.append(frozenset(j for j in range(n) if bits[j]))
+            prob += math.prod(p[j] if bits[j] else 1 - p[j] for j in range(n))
+    minimal = [s for s in true_sets if not any(t < s for t in true_sets)]
+    return sorted(sorted(s) for s in minimal), prob
+
+
+def csr_rows(row_ptr, col):
+    return sorted(list(col[row_ptr[i]:row_ptr[i + 1]]) for i in range(len(row_ptr) - 1))
+
+
+def test_example_tree_end_to_end_on_cpu(canopy_lib, oracle):
+    from canopy_amd.fault_tree import FaultTree
+    ft = FaultTree(path=EXAMPLE)
+    assert ft.top_gate_name == "TOP" and ft.info.n_basic_events == 7 and ft.info.n_house_events == 1
+    names = ft.basic_event_names
+    p = ft.probabilities()
+    assert dict(zip(names, p)) == {"pumpA": 0.1, "pumpB": 0.1, "pumpC": 0.1, "power": 0.02, "valve1": 0.05,
+                                   "valve2": 0.05, "leak": 1e-3}
+    row_ptr, col = ft.cut_sets()
+    got = sorted(sorted(names[c] for c in r) for r in csr_rows(row_ptr, col))
+    assert got == sorted([["leak"], ["pumpA", "pumpB"], ["pumpA", "pumpC"], ["pumpB", "pumpC"], ["power", "valve1"],
+                          ["power", "valve2"]])
+    for i in range(len(row_ptr) - 1):
+        assert np.all(np.diff(col[row_ptr[i]:row_ptr[i + 1]]) > 0)  # ascending: valid for canopy_model_upload
+    want_sets, exact = brute_force(ft.dag(), p)
+    assert csr_rows(row_ptr, col) == want_sets
+    q = oracle.quantify(row_ptr, col, p, cut_off=0.0)
+    assert abs(q.rare_event - 0.033) < 1e-15
+    assert q.rare_event >= q.mcub >= exact and abs(exact - 0.0308655046) < 1e-9
+    # limit_order drops nothing here at 2, keeps only {leak} at 1
+    assert len(ft.cut_sets(limit_order=2)[0]) == 7 and csr_rows(*ft.cut_sets(limit_order=1)) == [[names.index("leak")]]
+    # Monte-Carlo on the exported DAG agrees with the exact probability
+    hits = oracle.mc(ft.dag(), p, 5, 2_000_000, n_threads=4)
+    assert abs(hits / 2e6 - exact) < 5 * math.sqrt(exact * (1 - exact) / 2e6)
+
+
+MEF = """<opsa-mef><define-fault-tree name='t'>%s</define-fault-tree><model-data>%s</model-data></opsa-mef>"""
+
+
+def events(names, p=0.1):
+    return "".join("<define-basic-event name='%s'><float value='%g'/></define-basic-event>" % (n, p) for n in names)
+
+
+def test_house_events_fold_as_constants(canopy_lib):
+    from canopy_amd.fault_tree import FaultTree
+    gates = ("<define-gate name='top'><or><gate name='g1'/><gate name='g2'/></or></define-gate>"
+             "<define-gate name='g1'><and><basic-event name='a'/><house-event name='h'/></and></define-gate>"
+             "<define-gate name='g2'><and><basic-event name='b'/><basic-event name='c'/></and></define-gate>")
+    on = FaultTree(MEF % (gates, events("abc") + "<define-house-event name='h'><constant value='true'/></define-house-event>"))
+    off = FaultTree(MEF % (gates, events("abc") + "<define-house-event name='h'><constant value='false'/></define-house-event>"))
+    assert csr_rows(*on.cut_sets()) == [[0], [1, 2]]
+    assert csr_rows(*off.cut_sets()) == [[1, 2]]
+    # a house event that decides the top event outright
+    const = FaultTree(MEF % ("<define-gate name='top'><or><basic-event name='a'/><house-event name='h'/></or></define-gate>",
+                             events("a") + "<define-house-event name='h'><constant value='true'/></define-house-event>"))
+    row_ptr, col = const.cut_sets()
+    assert list(row_ptr) == [0, 0] and const.info.reserved == 2  # one empty cut set: TOP is TRUE
+
+
+@pytest.mark.parametrize("k,n", [(1, 3), (2, 4), (3, 5), (5, 5)])
+def test_atleast_expansion_matches_truth_table(canopy_lib, k, n):
+    from canopy_amd.fault_tree import FaultTree
+    names = [chr(ord("a") + i) for i in range(n)]
+    gate = "<define-gate name='top'><atleast min='%d'>%s</atleast></define-gate>" % (
+        k, "".join("<basic-event name='%s'/>" % x for x in names))
+    ft = FaultTree(MEF % (gate, events(names, 0.2)))
+    sets, _ = brute_force(ft.dag(), ft.probabilities())
+    assert csr_rows(*ft.cut_sets()) == sets and len(sets) == math.comb(n, k)
+
+
+def test_nested_tree_with_shared_events_is_minimised(canopy_lib):
+    from canopy_amd.fault_tree import FaultTree
+    gates = ("<define-gate name='top'><and><gate name='x'/><gate name='y'/></and></define-gate>"
+             "<define-gate name='x'><or><basic-event name='a'/><basic-event name='b'/></or></define-gate>"
+             "<define-gate name='y'><or><basic-event name='a'/><gate name='z'/></or></define-gate>"
+             "<define-gate name='z'><and><basic-event name='b'/><basic-event name='c'/></and></define-gate>")
+    ft = FaultTree(MEF % (gates, events("abc")))
+    sets, _ = brute_force(ft.dag(), ft.probabilities())
+    assert csr_rows(*ft.cut_sets()) == sets == [[0], [1, 2]]  # {a}, {b,c}; {a,b}, {a,b,c} are absorbed
+
+
+def test_non_coherent_tree_goes_to_the_dag_only(canopy_lib, oracle):
+    from canopy_amd import _capi
+    from canopy_amd.fault_tree import FaultTree
+    gates = ("<define-gate name='top'><and><basic-event name='a'/><gate name='n'/></and></define-gate>"
+             "<define-gate name='n'><not><basic-event name='b'/></not></define-gate>")
+    ft = FaultTree(MEF % (gates, events("ab", 0.3)))
+    with pytest.raises(_capi.CanopyError) as e:
+        ft.cut_sets()
+    assert e.value.status == _capi.ERR_UNSUPPORTED
+    _, exact = brute_force(ft.dag(), ft.probabilities())
+    assert abs(exact - 0.3 * 0.7) < 1e-15
+    hits = oracle.mc(ft.dag(), ft.probabilities(), 3, 1_000_000)
+    assert abs(hits / 1e6 - 0.21) < 5 * math.sqrt(0.21 * 0.79 / 1e6)
+
+
+@pytest.mark.parametrize("body,data,needle", [
+    ("<define-gate name='top'><or><gate name='g'/></or></define-gate>", events("a"), "never defined"),
+    ("<define-gate name='top'><or><basic-event name='a'/></or></define-gate>", "", "no probability"),
+    ("<define-gate name='t1'><or><basic-event name='a'/></or></define-gate>"
+     "<define-gate name='t2'><or><basic-event name='a'/></or></define-gate>", events("a"), "more than one top"),
+    ("<define-gate name='g1'><or><gate name='g2'/></or></define-gate>"
+     "<define-gate name='g2'><or><gate name='g1'/></or></define-gate>", events("a"), "cycle"),
+    ("<define-gate name='top'><atleast min='4'><basic-event name='a'/><basic-event name='b'/></atleast></define-gate>",
+     events("ab"), "min out of range"),
+    ("<define-gate name='top'><or><basic-event name='a'/></or></define-gate>",
+     "<define-basic-event name='a'><float value='1.5'/></define-basic-event>", "outside [0,1]"),
+])
+def test_malformed_models_are_rejected_with_a_message(canopy_lib, body, data, needle):
+    from canopy_amd import _capi
+    from canopy_amd.fault_tree import FaultTree
+    with pytest.raises(_capi.CanopyError) as e:
+        FaultTree(MEF % (body, data))
+    assert e.value.status == _capi.ERR_INVALID_MODEL and needle in str(e.value)
+
+
+def test_xml_reader_tolerates_comments_declarations_and_quotes(canopy_lib):
+    from canopy_amd import _capi
+    from canopy_amd.fault_tree import FaultTree
+    text = ('<?xml version="1.0"?>\n<!DOCTYPE opsa-mef>\n<!-- c --><opsa-mef>\n <define-fault-tree name="t">'
+            '<label>text is ignored</label><define-gate name="top"> <or> <basic-event name=\'a\' /><!-- x -->'
+            '<basic-event name="b"/></or></define-gate></define-fault-tree>' + "<model-data>" + events("ab") +
+            "</model-data></opsa-mef>")
+    assert csr_rows(*FaultTree(text).cut_sets()) == [[0], [1]]
+    for broken in ("<opsa-mef><define-gate name='x'>", "<other/>", "<opsa-mef><a></b></opsa-mef>", ""):
+        with pytest.raises(_capi.CanopyError):
+            FaultTree(broken)
+
+
+@pytest.mark.gpu
+def test_example_tree_through_the_gpu_paths(gpu_ctx, oracle):
+    """Config 1 end to end on the device: MEF -> CSR -> canopy_quantify, and MEF -> DAG -> canopy_mc_run."""
+    from canopy_amd import default_params
+    from canopy_amd.fault_tree import FaultTree
+    from canopy_amd.quantifier import Dag
+    ft = FaultTree(path=EXAMPLE)
+    p = ft.probabilities()
+    row_ptr, col = ft.cut_sets()
+    model = gpu_ctx.upload(row_ptr, col, ft.info.n_basic_events)
+    model.set_probabilities(p)
+    got = gpu_ctx.quantify(model, default_params(cut_off=0.0))
+    want = oracle.quantify(row_ptr, col, p, cut_off=0.0)
+    assert got.n_kept == 6 and got.argmax_row == int(want.argmax_row)
+    assert abs(got.rare_event - want.rare_event) <= 1e-12 * want.rare_event
+    assert abs(got.mcub - want.mcub) <= 1e-12 * want.mcub
+    model.close()
+    d = Dag(gpu_ctx, ft.dag())
+    d.set_probabilities(p)
+    r = d.run(7, 3_000_000)
+    assert r.hits == oracle.mc(ft.dag(), p, 7, 3_000_000, n_threads=4)
+    assert abs(r.estimate - 0.0308655046) < 5 * r.std_error
+    d.close()
