@@ -232,10 +232,13 @@ __global__ __launch_bounds__(WsCfg<RW>::waves * kWave) void k_ws(const uint4* __
                 }                                                                                      \
                 if (!done) {                                                                           \
                     const uint32_t e[4] = {QC[k].x, QC[k].y, QC[k].z, QC[k].w};                        \
+                    double* dst[4]; /* all four slot addresses first: keeps dependent issues apart */   \
+                    _Pragma("unroll") for (int u = 0; u < 4; ++u) dst[u] = &sums[e[u] & ((1u << C::row_bits) - 1)]; \
+                    __builtin_amdgcn_sched_barrier(0);                                                 \
                     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                    \
                         if (ABL & 2) asm volatile("" ::"v"(v[k][u]), "v"(e[u]));                       \
                         else                                                                           \
-                            __hip_atomic_fetch_add(&sums[e[u] & ((1u << C::row_bits) - 1)], v[k][u], __ATOMIC_RELAXED,  \
+                            __hip_atomic_fetch_add(dst[u], v[k][u], __ATOMIC_RELAXED,                   \
                                                    __HIP_MEMORY_SCOPE_WAVEFRONT);                      \
                     }                                                                                  \
                     --rem;                                                                             \
