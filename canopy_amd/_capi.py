@@ -28,7 +28,7 @@ UPLOAD_DEVICE_POINTERS = 2
 APPROX_RARE_EVENT, APPROX_MCUB, APPROX_BOTH = 1, 2, 3
 QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK = 1, 2, 4
 GATE_AND, GATE_OR, GATE_ATLEAST, GATE_XOR, GATE_NOT, GATE_NAND, GATE_NOR, GATE_NULL = range(8)
-KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER, KERNEL_FILTER_REFINE = range(6)
 
 
 class CtxParams(C.Structure):

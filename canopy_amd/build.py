@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcanopy.so")
 
-SOURCES = ["canopy_api.hip", "kernels_rows.hip", "kernels_build.hip", "kernels_ws.hip", "kernels_vs.hip", "kernels_mc.hip", "mef_lowering.cpp"]
+SOURCES = ["canopy_api.hip", "kernels_rows.hip", "kernels_build.hip", "kernels_ws.hip", "kernels_vs.hip", "kernels_mc.hip", "kernels_fr.hip", "mef_lowering.cpp"]
 HEADERS = ["canopy_device.h", "canopy_internal.h"]
 
 FLAGS = [

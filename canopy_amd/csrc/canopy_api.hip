@@ -57,6 +57,9 @@ void free_model_buffers(canopy_model* m) {
     if (m->d_vs_stream) (void)hipFree(m->d_vs_stream);
     if (m->d_vs_off) (void)hipFree(m->d_vs_off);
     if (m->d_vs_slab_row) (void)hipFree(m->d_vs_slab_row);
+    if (m->d_fr_stream) (void)hipFree(m->d_fr_stream);
+    if (m->d_fr_off) (void)hipFree(m->d_fr_off);
+    m->d_fr_stream = nullptr; m->d_fr_off = nullptr; m->fr_state = 0;
     m->d_vs_stream = nullptr; m->d_vs_off = nullptr; m->d_vs_slab_row = nullptr; m->vs_state = 0;
     m->d_row_ptr = nullptr; m->d_col_idx = nullptr; m->d_logp = nullptr;
     m->d_ws_stream = nullptr; m->d_ws_off = nullptr; m->ws_state = 0;
@@ -299,7 +302,10 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
     info->n_events = m->n_events; info->max_row_len = m->max_row_len;
     info->device_bytes = m->device_bytes;
     info->stream_bytes = 0;
-    if (m->vs_state == 1)
+    if (m->fr_state == 1)
+        info->stream_bytes = m->fr_total_chunks * 1024 + (m->n_fr_slabs + 1) * 8 + (m->n_rows + 63) / 64 * 16 +
+                             (int64_t)m->n_events * 8;
+    else if (m->vs_state == 1)
         info->stream_bytes = m->vs_total_chunks * 1024 + (m->n_slabs + 1) * 16 + (m->n_rows + 1) * 8 + (int64_t)m->n_events * 8;
     else if (m->ws_state == 1)
         info->stream_bytes = m->ws_total_chunks * 1024 + (m->n_ws + 1) * 8 + (int64_t)m->n_events * 8;
@@ -344,6 +350,16 @@ int auto_variant(const canopy_model* m) {
     return CANOPY_KERNEL_ROWS;
 }
 
+canopy_status build_fr(canopy_ctx* ctx, canopy_model* m) {
+    if (m->fr_state != 0) return CANOPY_OK;
+    bool ok = false;
+    HIP_TRY(ctx, fr_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, m->max_row_len, &m->d_fr_stream,
+                          &m->d_fr_off, &m->fr_total_chunks, &m->n_fr_slabs, &ok, ctx->stream));
+    m->fr_state = ok ? 1 : -1;
+    if (ok) m->device_bytes += (m->fr_total_chunks + 1) * 1024 + (m->n_fr_slabs + 1) * 8;
+    return CANOPY_OK;
+}
+
 canopy_status build_vs(canopy_ctx* ctx, canopy_model* m) {
     if (m->vs_state != 0) return CANOPY_OK;
     bool ok = false;
@@ -373,6 +389,12 @@ extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int variant = kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : kernel;
     if (variant == CANOPY_KERNEL_ROWS || variant == CANOPY_KERNEL_ROWS_LDS) return CANOPY_OK;
+    if (variant == CANOPY_KERNEL_FILTER_REFINE) {
+        canopy_status st = build_fr(ctx, m);
+        if (st != CANOPY_OK) return st;
+        if (m->fr_state != 1) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a filter/refine stream");
+        return CANOPY_OK;
+    }
     if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
         canopy_status st = build_vs(ctx, m);
         if (st != CANOPY_OK) return st;
@@ -386,6 +408,10 @@ extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, 
     if (st != CANOPY_OK) return st;
     if (m->ws_state != 1 && kernel == CANOPY_KERNEL_WAVE_STREAM)
         return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a wave-slab stream");
+    if (kernel == CANOPY_KERNEL_AUTO && m->n_events <= fr_max_events()) { // AUTO may pick FR for cut_off > 0
+        st = build_fr(ctx, m);
+        if (st != CANOPY_OK) return st;
+    }
     return CANOPY_OK;
 }
 
@@ -401,9 +427,24 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "limit_order < 0 or cut_off < 0");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
+    const bool want_rows_early = (params->flags & CANOPY_QUANT_ROW_LOGP) != 0;
     int variant = params->kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : params->kernel;
+    // AUTO: with a positive cut-off and no per-row output, filter/refine replaces the wave-slab stream
+    if (params->kernel == CANOPY_KERNEL_AUTO && variant == CANOPY_KERNEL_WAVE_STREAM && params->cut_off > 0.0 &&
+        !want_rows_early && m->n_events <= fr_max_events()) {
+        canopy_status pst = build_fr(ctx, const_cast<canopy_model*>(m));
+        if (pst != CANOPY_OK) return pst;
+        if (m->fr_state == 1) variant = CANOPY_KERNEL_FILTER_REFINE;
+    }
+    if (variant == CANOPY_KERNEL_FILTER_REFINE) {
+        if (!(params->cut_off > 0.0) || want_rows_early)
+            return fail(ctx, CANOPY_ERR_UNSUPPORTED, "FILTER_REFINE needs cut_off > 0 and no per-row output");
+        canopy_status pst = build_fr(ctx, const_cast<canopy_model*>(m));
+        if (pst != CANOPY_OK) return pst;
+        if (m->fr_state != 1) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a filter/refine stream");
+    }
     if (variant != CANOPY_KERNEL_ROWS && variant != CANOPY_KERNEL_ROWS_LDS && variant != CANOPY_KERNEL_WAVE_STREAM &&
-        variant != CANOPY_KERNEL_VALUE_SCATTER)
+        variant != CANOPY_KERNEL_VALUE_SCATTER && variant != CANOPY_KERNEL_FILTER_REFINE)
         return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
     if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
         canopy_status pst = build_vs(ctx, const_cast<canopy_model*>(m)); // lazy, one-off, independent of p
@@ -435,7 +476,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         ctx->row_logp_cap = m->n_rows;
     }
     const int64_t n_words = (m->n_rows + 63) / 64;
-    if (want_mask && ctx->keep_mask_cap < n_words) {
+    if ((want_mask || variant == CANOPY_KERNEL_FILTER_REFINE) && ctx->keep_mask_cap < n_words) {
         if (ctx->d_keep_mask) (void)hipFree(ctx->d_keep_mask);
         ctx->d_keep_mask = nullptr; ctx->keep_mask_cap = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_keep_mask, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1)));
@@ -447,6 +488,8 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : ws_default_grid(ctx->n_cu, m->n_ws);
     else if (variant == CANOPY_KERNEL_VALUE_SCATTER)
         grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : vs_default_grid(ctx->n_cu, m->n_slabs);
+    else if (variant == CANOPY_KERNEL_FILTER_REFINE)
+        grid = fr_refine_grid(ctx->n_cu);
     else
         grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override
                                           : rows_kernel_default_grid(ctx->n_cu, variant, m->n_rows);
@@ -473,7 +516,13 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
     }
     HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
-    if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
+    if (variant == CANOPY_KERNEL_FILTER_REFINE) {
+        // delta covers the rounding difference between the unordered pass-A sum and the CSR-order sum
+        const double cand_cut = a.log_cut - (1e-9 + 1e-11 * (double)m->max_row_len);
+        HIP_TRY(ctx, launch_fr_filter(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, m->n_rows,
+                                      m->n_events, m->n_fr_slabs, cand_cut, ctx->d_keep_mask, ctx->n_cu, ctx->stream));
+        HIP_TRY(ctx, launch_fr_refine(a, ctx->d_keep_mask, n_words, want_mask ? 1 : 0, grid, ctx->stream));
+    } else if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
         HIP_TRY(ctx, launch_vs_kernel(a, m->d_vs_stream, m->d_vs_off, m->d_vs_slab_row, m->vs_total_chunks, m->n_slabs,
                                       grid, ctx->stream));
     } else if (variant == CANOPY_KERNEL_WAVE_STREAM) {

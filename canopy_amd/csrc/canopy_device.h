@@ -112,14 +112,28 @@ __device__ __forceinline__ void acc_load(Acc& a, const double* src) {
     a.n_kept = src[4]; a.n_certain = src[5]; a.max_logp = src[6]; a.argmax = src[7];
 }
 
+// Contribution of one kept row to the two compensated sums: P = exp(s), log1p(-P).
+// For P < 2^-12 (every realistic rare-event cut set) log1p(-P) = -P(1 + P/2 + P^2/3 + P^3/4 + P^4/5 + P^5/6)
+// is exact to < 1e-19 relative; ocml's log1p runs only when some lane of the wave needs it.
+__device__ __forceinline__ void fold_kept_row(CSum& rare, CSum& l1p, double& n_certain, double s, bool on) {
+    const double P = on ? exp(s) : 0.0;
+    double l = -P * (1.0 + P * (0.5 + P * (1.0 / 3.0 + P * (0.25 + P * (0.2 + P * (1.0 / 6.0))))));
+    const bool big = on && P >= 0x1.0p-12;
+    if (__any(big)) {
+        if (big) l = (P < 1.0) ? log1p(-P) : 0.0;
+    }
+    if (on) {
+        csum_add(rare, P);
+        if (P < 1.0) csum_add(l1p, l); else n_certain += 1.0;
+    }
+}
+
 // Per-row epilogue shared by every row kernel: filter, P = exp(s), both sums, argmax.
 __device__ __forceinline__ bool row_epilogue(Acc& a, double s, int len, bool valid, double log_cut,
                                             int limit_order, double global_row) {
     const bool keep = valid && (s >= log_cut) && (limit_order == 0 || len <= limit_order);
+    fold_kept_row(a.rare, a.l1p, a.n_certain, s, keep);
     if (keep) {
-        const double P = exp(s);
-        csum_add(a.rare, P);
-        if (P < 1.0) csum_add(a.l1p, log1p(-P)); else a.n_certain += 1.0;
         a.n_kept += 1.0;
         if (s > a.max_logp) { a.max_logp = s; a.argmax = global_row; }
     }

@@ -79,6 +79,11 @@ struct canopy_model {
     int64_t* d_vs_slab_row = nullptr;
     int64_t vs_total_chunks = 0, n_slabs = 0;
     int vs_state = 0;
+    // derived filter/refine slab stream (kernels_fr.hip)
+    uint32_t* d_fr_stream = nullptr;
+    int64_t* d_fr_off = nullptr;
+    int64_t fr_total_chunks = 0, n_fr_slabs = 0;
+    int fr_state = 0;
 };
 
 namespace canopy {
@@ -136,5 +141,18 @@ hipError_t vs_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
                     int64_t* total_chunks_out, int64_t* n_slabs_out, bool* ok, hipStream_t s);
 hipError_t launch_vs_kernel(const RowKernelArgs& ra, const uint32_t* stream, const int64_t* vs_off,
                             const int64_t* slab_row, int64_t total_chunks, int64_t n_slabs, int grid, hipStream_t s);
+
+
+// kernels_fr.hip
+int fr_max_events();
+int fr_refine_grid(int n_cu);
+hipError_t fr_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events,
+                    int32_t max_row_len, uint32_t** d_stream_out, int64_t** d_fr_off_out, int64_t* total_chunks_out,
+                    int64_t* n_slabs_out, bool* ok, hipStream_t s);
+hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
+                            int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint64_t* cand_mask,
+                            int n_cu, hipStream_t s);
+hipError_t launch_fr_refine(const RowKernelArgs& a, uint64_t* mask, int64_t n_words, int write_mask, int grid,
+                            hipStream_t s);
 
 } // namespace canopy

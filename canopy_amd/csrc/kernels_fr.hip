@@ -1,0 +1,373 @@
+// kernels_fr.hip -- "filter then refine" (FR) variant of K1..K4 for large basic-event counts and a
+// positive cut-off, gfx950 / wave64 only.
+//
+// With the reference's default cut_off = 1e-8 (settings.h:332) fewer than 1 % of the cut sets survive
+// the filter s_i >= log(cut_off). Everything the path reports (sums, count, argmax, keep mask) depends
+// on the survivors only. So:
+//
+//   pass A  k_fr_filter: an UNCONSTRAINED fast pass over all entries whose only job is to find the rows
+//           that might survive. A workgroup (8 waves; two workgroups per CU) owns a slab of 8192
+//           consecutive rows whose running sums live in LDS; the slab's entries arrive as a
+//           column-ordered stream of packed u32 (col << 14 | row_local) built once at prepare time, any
+//           wave takes any chunk: 64 gathers of neighbouring columns, then 64 unordered ds_add_f64.
+//           The order of additions is NOT the CSR order here, so s~_i differs from s_i by rounding only
+//           (<= len * 2^-53 * sum|logp|, about 1e-13). Rows with s~_i >= log(cut_off) - delta
+//           (delta = 1e-9 >> that error) are flagged in a candidate bitmask.
+//   pass B  k_fr_refine: every candidate row is recomputed from the canonical CSR in exact CSR order
+//           (the same plain v_add_f64 chain as the oracle) and goes through the exact filter, exp / log1p
+//           sums, count, argmax, keep mask. No row that survives exactly can be missed (its s~ is within
+//           1e-13 of s >= log(cut_off)), and no reported value comes from pass A.
+//
+// Per-row log-probability output needs every s_i exactly and therefore uses the WAVE_STREAM kernel.
+#include <stdlib.h>
+
+#include "canopy_device.h"
+#include "canopy_internal.h"
+
+namespace canopy {
+
+namespace {
+
+constexpr int kFrChunk = 256;
+
+int grid_for(int64_t n, int block) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// configuration: rows per slab (the slot after them is the no-op sink), waves per workgroup
+template <int SLAB_ROWS>
+struct FrCfg {
+    static constexpr int slab_rows = SLAB_ROWS;
+    static constexpr int row_bits = SLAB_ROWS > 8192 ? 15 : 14;
+    static constexpr uint32_t row_mask = (1u << row_bits) - 1;
+    static constexpr int slots = SLAB_ROWS + 64;
+    static constexpr int waves = SLAB_ROWS / 1024; // 8192 rows: 8 waves, two workgroups per CU; 16384: 16 waves
+    static constexpr int threads = waves * kWave;
+    static constexpr size_t lds = (size_t)slots * 8;
+};
+
+// 16384-row slabs (one 16-wave workgroup per CU) measured faster than 8192-row slabs (two 8-wave
+// workgroups): 0.85 vs 0.98 ms at config 3. They need 15 row bits, i.e. E <= 2^17; beyond that 8192.
+int fr_slab_rows_for(int32_t n_events) {
+    static const int forced = getenv("CANOPY_FR_SLAB") ? atoi(getenv("CANOPY_FR_SLAB")) : 0; // tuning only
+    if (forced == 8192 || forced == 16384) return forced;
+    return n_events <= (1 << 17) ? 16384 : 8192;
+}
+
+// ---- builder: one thread per slab, greedy placement of the slab's entries into 64-entry groups by
+// column (target group = the column's share of the slab's group count, spill forward when full)
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_fr_build(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                                 int64_t n_rows, int32_t n_events, int slab_rows, int row_bits,
+                                                 int64_t n_slabs, int gcap,
+                                                 uint8_t* cnt_scratch, int64_t* chunks, const int64_t* __restrict__ fr_off,
+                                                 uint32_t* stream, int* overflow) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slabs) return;
+    const int64_t r0 = s * slab_rows;
+    const int64_t r1 = r0 + slab_rows < n_rows ? r0 + slab_rows : n_rows;
+    const int64_t nnz = row_ptr[r1] - row_ptr[r0];
+    int64_t ng_nom = (nnz + 63) / 64;
+    if (ng_nom < 1) ng_nom = 1;
+    uint8_t* cnt = cnt_scratch + (size_t)s * gcap;
+    for (int g = 0; g < gcap; ++g) cnt[g] = 0;
+    int g_max = -1;
+    const int64_t base = WRITE ? fr_off[s] * kFrChunk : 0;
+    bool ovf = false;
+    for (int64_t r = r0; r < r1 && !ovf; ++r) {
+        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
+            const uint32_t c = (uint32_t)col_idx[k];
+            int g = (int)(((uint64_t)c * (uint64_t)ng_nom) / (uint64_t)n_events);
+            while (g < gcap && cnt[g] >= 64) ++g;
+            if (g >= gcap) { ovf = true; break; }
+            const int slot = cnt[g]++;
+            if (WRITE) stream[base + (int64_t)(g >> 2) * kFrChunk + slot * 4 + (g & 3)] = (c << row_bits) | (uint32_t)(r - r0);
+            g_max = g > g_max ? g : g_max;
+        }
+    }
+    if (ovf) atomicExch(overflow, 1);
+    if (!WRITE) chunks[s] = (int64_t)((g_max + 1 + 3) / 4);
+}
+
+// largest number of entries any slab holds (sizes the builder's group counters)
+__global__ __launch_bounds__(256) void k_fr_max_nnz(const int64_t* __restrict__ row_ptr, int64_t n_rows, int slab_rows,
+                                                    int64_t n_slabs, unsigned long long* out) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slabs) return;
+    const int64_t r0 = s * slab_rows;
+    const int64_t r1 = r0 + slab_rows < n_rows ? r0 + slab_rows : n_rows;
+    atomicMax(out, (unsigned long long)(row_ptr[r1] - row_ptr[r0]));
+}
+
+__global__ __launch_bounds__(256) void k_fr_fill(uint32_t* p, int64_t n, uint32_t v) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+__device__ __forceinline__ int64_t fr_uload(const int64_t* __restrict__ p) {
+    const int64_t v = *p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
+
+__device__ __forceinline__ void fr_barrier() { // LDS drained, then the workgroup barrier (no vmcnt drain)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---- pass A ------------------------------------------------------------------------------------------
+template <int SLAB_ROWS, int kFrU>
+__global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const uint4* __restrict__ stream,
+                                                             const int64_t* __restrict__ fr_off, int64_t total_chunks,
+                                                             const double* __restrict__ logp, int64_t n_rows,
+                                                             int64_t n_slabs, double cand_cut,
+                                                             uint64_t* __restrict__ cand_mask) {
+    using Cf = FrCfg<SLAB_ROWS>;
+    constexpr int kFrRowBits = Cf::row_bits, kFrSlabRows = Cf::slab_rows, kFrSlots = Cf::slots, kFrWaves = Cf::waves,
+                  kFrThreads = Cf::threads;
+    constexpr uint32_t kFrRowMask = Cf::row_mask;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sums = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    for (int i = tid; i < kFrSlots; i += kFrThreads) sums[i] = 0.0;
+    fr_barrier();
+
+    const int64_t G = (int64_t)gridDim.x;
+    for (int64_t s = (int64_t)blockIdx.x; s < n_slabs; s += G) {
+        const int64_t c0 = fr_uload(fr_off + s), c1 = fr_uload(fr_off + s + 1);
+        // -------- phase 1: any wave, any chunk: gather, unordered LDS add
+        uint4 q[kFrU];
+#pragma unroll
+        for (int u = 0; u < kFrU; ++u) {
+            const int64_t c = c0 + wave + (int64_t)u * kFrWaves;
+            q[u] = stream[(c < c1 ? c : total_chunks) * kWave + lane]; // past the end: the no-op chunk
+        }
+        for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)kFrU * kFrWaves) {
+            double v[kFrU][4];
+#pragma unroll
+            for (int u = 0; u < kFrU; ++u) {
+                const uint32_t e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[u][k] = logp[e[k] >> kFrRowBits];
+            }
+            uint4 qn[kFrU]; // next step's chunks: issued behind the gathers, so the adds do not wait for them
+#pragma unroll
+            for (int u = 0; u < kFrU; ++u) {
+                const int64_t c = cb + (int64_t)(kFrU + u) * kFrWaves;
+                qn[u] = stream[(c < c1 ? c : total_chunks) * kWave + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < kFrU; ++u) {
+                const uint32_t e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    __hip_atomic_fetch_add(&sums[e[k] & kFrRowMask], v[u][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (int u = 0; u < kFrU; ++u) q[u] = qn[u];
+        }
+        fr_barrier();
+        // -------- phase 2: flag the rows that might survive, clear the sums
+        const int64_t r0 = s * kFrSlabRows;
+#pragma unroll 4
+        for (int i = 0; i < kFrSlabRows / kFrThreads; ++i) {
+            const int rl = i * kFrThreads + tid;
+            const double sv = sums[rl];
+            sums[rl] = 0.0;
+            const int64_t r = r0 + rl;
+            const unsigned long long m = __ballot(r < n_rows && sv >= cand_cut);
+            if (lane == 0 && r < n_rows) cand_mask[r >> 6] = m;
+        }
+        if (tid < 64) sums[kFrSlabRows + tid] = 0.0; // the sink
+        fr_barrier();
+    }
+}
+
+// ---- pass B ------------------------------------------------------------------------------------------
+// One lane per mask word (64 rows): the lane walks the word's candidate bits; each candidate row is
+// summed from the canonical CSR in CSR order. Fixed lane <- word assignment => reproducible.
+__global__ __launch_bounds__(256) void k_fr_refine(RowKernelArgs a, uint64_t* __restrict__ mask /* in: candidates, out: keep */,
+                                                   int64_t n_words, int write_mask) {
+    __shared__ double s_red[4 * kAccDoubles];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    Acc acc;
+    acc_init(acc);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + tid; w < n_words; w += stride) {
+        unsigned long long m = mask[w];
+        unsigned long long keep_bits = 0ULL;
+        while (m != 0ULL) {
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1;
+            const int64_t r = w * 64 + bit;
+            const int64_t b = a.row_ptr[r], e = a.row_ptr[r + 1];
+            double s = 0.0;
+            for (int64_t k = b; k < e; ++k) s = s + a.logp[a.col_idx[k]]; // CSR order, plain adds
+            const int len = (int)(e - b);
+            const bool keep = (s >= a.log_cut) && (a.limit_order == 0 || len <= a.limit_order);
+            if (keep) {
+                keep_bits |= 1ULL << bit;
+                const double P = exp(s);
+                csum_add(acc.rare, P);
+                if (P < 1.0) csum_add(acc.l1p, log1p(-P)); else acc.n_certain += 1.0;
+                acc.n_kept += 1.0;
+                if (s > acc.max_logp) { acc.max_logp = s; acc.argmax = (double)(a.row_offset + r); }
+            }
+        }
+        if (write_mask) mask[w] = keep_bits;
+    }
+    acc_wave_reduce(acc);
+    if (lane == 0) acc_store(s_red + wave * kAccDoubles, acc);
+    __syncthreads();
+    if (tid == 0) {
+        Acc t;
+        acc_load(t, s_red);
+        for (int k = 1; k < 4; ++k) {
+            Acc o;
+            acc_load(o, s_red + k * kAccDoubles);
+            acc_merge(t, o);
+        }
+        acc_store(a.block_partials + (size_t)blockIdx.x * kAccDoubles, t);
+    }
+}
+
+} // namespace
+
+int fr_max_events() { return 1 << 18; }
+int fr_refine_grid(int n_cu) { return n_cu * 8; }
+
+hipError_t fr_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events,
+                    int32_t max_row_len, uint32_t** d_stream_out, int64_t** d_fr_off_out, int64_t* total_chunks_out,
+                    int64_t* n_slabs_out, bool* ok, hipStream_t s) {
+    *ok = false;
+    if (n_events > fr_max_events() || n_events < 1) return hipSuccess;
+    const int slab_rows = fr_slab_rows_for(n_events), row_bits = slab_rows > 8192 ? 15 : 14;
+    const int64_t n_slabs = (n_rows + slab_rows - 1) / slab_rows;
+    *n_slabs_out = n_slabs;
+    (void)max_row_len;
+    int64_t max_nnz = 0;
+    if (n_slabs > 0) {
+        unsigned long long* d_max = nullptr;
+        hipError_t e0 = hipMalloc(&d_max, sizeof(unsigned long long));
+        if (e0 != hipSuccess) return e0;
+        e0 = hipMemsetAsync(d_max, 0, sizeof(unsigned long long), s);
+        if (e0 == hipSuccess) {
+            hipLaunchKernelGGL(k_fr_max_nnz, dim3(grid_for(n_slabs, 256)), dim3(256), 0, s, d_row_ptr, n_rows, slab_rows,
+                               n_slabs, d_max);
+            e0 = hipGetLastError();
+        }
+        unsigned long long h_max = 0;
+        if (e0 == hipSuccess) e0 = hipMemcpyAsync(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost, s);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(s);
+        (void)hipFree(d_max);
+        if (e0 != hipSuccess) return e0;
+        max_nnz = (int64_t)h_max;
+    }
+    int64_t gcap64 = (max_nnz + 63) / 64;
+    gcap64 = gcap64 + gcap64 / 4 + 32;
+    if (gcap64 > (1 << 22)) return hipSuccess;
+    const int gcap = (int)gcap64;
+    int64_t* d_off = nullptr;
+    uint8_t* d_cnt = nullptr;
+    int* d_ovf = nullptr;
+    uint32_t* d_stream = nullptr;
+    auto bail = [&](hipError_t err) {
+        if (d_off) (void)hipFree(d_off);
+        if (d_cnt) (void)hipFree(d_cnt);
+        if (d_ovf) (void)hipFree(d_ovf);
+        if (d_stream) (void)hipFree(d_stream);
+        return err;
+    };
+    hipError_t e = hipMalloc(&d_off, sizeof(int64_t) * (size_t)(n_slabs + 1));
+    if (e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)(n_slabs > 0 ? n_slabs : 1) * gcap);
+    if (e == hipSuccess) e = hipMalloc(&d_ovf, sizeof(int));
+    if (e != hipSuccess) return bail(e);
+    e = hipMemsetAsync(d_ovf, 0, sizeof(int), s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_off, 0, sizeof(int64_t), s);
+    if (e != hipSuccess) return bail(e);
+    int ovf = 0;
+    int64_t total = 0;
+    if (n_slabs > 0) {
+        hipLaunchKernelGGL((k_fr_build<false>), dim3(grid_for(n_slabs, 64)), dim3(64), 0, s, d_row_ptr, d_col_idx, n_rows,
+                           n_events, slab_rows, row_bits, n_slabs, gcap, d_cnt, d_off + 1, (const int64_t*)nullptr, (uint32_t*)nullptr, d_ovf);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = scan_inclusive_i64(d_off + 1, n_slabs, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&ovf, d_ovf, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, d_off + n_slabs, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return bail(e);
+    if (ovf) { (void)bail(hipSuccess); return hipSuccess; }
+    const int64_t n_entries = (total + 1) * kFrChunk;
+    e = hipMalloc(&d_stream, sizeof(uint32_t) * (size_t)n_entries);
+    if (e != hipSuccess) return bail(e);
+    int fg = grid_for(n_entries, 256);
+    if (fg > 4096) fg = 4096;
+    hipLaunchKernelGGL(k_fr_fill, dim3(fg), dim3(256), 0, s, d_stream, n_entries, (uint32_t)slab_rows); // col 0 -> sink
+    if (n_slabs > 0) {
+        hipLaunchKernelGGL((k_fr_build<true>), dim3(grid_for(n_slabs, 64)), dim3(64), 0, s, d_row_ptr, d_col_idx, n_rows,
+                           n_events, slab_rows, row_bits, n_slabs, gcap, d_cnt, (int64_t*)nullptr, (const int64_t*)d_off, d_stream, d_ovf);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return bail(e);
+    (void)hipFree(d_cnt);
+    (void)hipFree(d_ovf);
+    *d_stream_out = d_stream;
+    *d_fr_off_out = d_off;
+    *total_chunks_out = total;
+    *ok = true;
+    return hipSuccess;
+}
+
+namespace {
+template <int SLAB_ROWS, int U>
+hipError_t launch_fr_filter_t(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
+                              int64_t n_rows, int64_t n_slabs, double cand_cut, uint64_t* cand_mask, int n_cu,
+                              hipStream_t s) {
+    using Cf = FrCfg<SLAB_ROWS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter<SLAB_ROWS, U>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int64_t grid = (int64_t)n_cu * (SLAB_ROWS > 8192 ? 1 : 2);
+    if (grid > n_slabs) grid = n_slabs;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((k_fr_filter<SLAB_ROWS, U>), dim3((unsigned)grid), dim3(Cf::threads), Cf::lds, s,
+                       reinterpret_cast<const uint4*>(stream), fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut,
+                       cand_mask);
+    return hipGetLastError();
+}
+} // namespace
+
+hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
+                            int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint64_t* cand_mask,
+                            int n_cu, hipStream_t s) {
+    static const int u = getenv("CANOPY_FR_U") ? atoi(getenv("CANOPY_FR_U")) : 4; // tuning only
+    if (fr_slab_rows_for(n_events) == 16384) {
+        if (u == 1) return launch_fr_filter_t<16384, 1>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
+        if (u == 4) return launch_fr_filter_t<16384, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
+        if (u == 2) return launch_fr_filter_t<16384, 2>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
+        return launch_fr_filter_t<16384, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
+    }
+    if (u == 1) return launch_fr_filter_t<8192, 1>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
+    if (u == 4) return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
+    if (u == 2) return launch_fr_filter_t<8192, 2>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
+    return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
+}
+
+hipError_t launch_fr_refine(const RowKernelArgs& a, uint64_t* mask, int64_t n_words, int write_mask, int grid,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(k_fr_refine, dim3(grid), dim3(256), 0, s, a, mask, n_words, write_mask);
+    return hipGetLastError();
+}
+
+} // namespace canopy

@@ -48,11 +48,7 @@ struct RowsFold { CSum rare, l1p; double n_certain; };
 // exp / log1p / compensated sums for 64 queued kept rows (not inlined: keeps the transcendental
 // code's registers out of the streaming loop)
 __device__ __noinline__ RowsFold rows_fold(RowsFold f, double s, bool on) {
-    if (on) {
-        const double P = exp(s);
-        csum_add(f.rare, P);
-        if (P < 1.0) csum_add(f.l1p, log1p(-P)); else f.n_certain += 1.0;
-    }
+    fold_kept_row(f.rare, f.l1p, f.n_certain, s, on);
     return f;
 }
 

@@ -122,11 +122,7 @@ __device__ __forceinline__ void vs_barrier() { // LDS drained, then the workgrou
 // (not inlined: keeps the transcendental code's registers out of the streaming loop)
 struct FoldState { CSum rare, l1p; double n_certain; };
 __device__ __noinline__ FoldState vs_fold(FoldState f, double s, bool on) {
-    if (on) {
-        const double P = exp(s);
-        csum_add(f.rare, P);
-        if (P < 1.0) csum_add(f.l1p, log1p(-P)); else f.n_certain += 1.0;
-    }
+    fold_kept_row(f.rare, f.l1p, f.n_certain, s, on);
     return f;
 }
 #define VS_FOLD(ACC, S, ON)                                            \

@@ -157,12 +157,8 @@ __device__ __noinline__ void ws_epilogue(double* sums, int64_t t, int lane, Acc*
     for (int j = 0; j < n_comp; j += kWave) {
         const bool on = j + lane < n_comp;
         const double sv = on ? sums[comp_base + j + lane] : 0.0;
-        if (on) {
-            sums[comp_base + j + lane] = 0.0;
-            const double P = exp(sv);
-            csum_add(acc.rare, P);
-            if (P < 1.0) csum_add(acc.l1p, log1p(-P)); else acc.n_certain += 1.0;
-        }
+        if (on) sums[comp_base + j + lane] = 0.0;
+        fold_kept_row(acc.rare, acc.l1p, acc.n_certain, sv, on);
     }
     if (it_begin == 0) sums[RW + lane] = 0.0; // the sink
     *acc_io = acc;

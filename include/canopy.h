@@ -189,8 +189,11 @@ enum {
     CANOPY_KERNEL_ROWS_LDS = 2, /* same, logp table resident in LDS (needs E*8 B <= table budget) */
     CANOPY_KERNEL_WAVE_STREAM = 3, /* derived layout: per-wave column-ordered entry stream, row sums in
                                       LDS (large E); built once by canopy_model_prepare */
-    CANOPY_KERNEL_VALUE_SCATTER = 4 /* derived layout: per-slab column-ordered entry stream, gathered
-                                       values scattered to CSR slots in LDS, lane-per-row sums (large E) */
+    CANOPY_KERNEL_VALUE_SCATTER = 4, /* derived layout: per-slab column-ordered entry stream, gathered
+                                        values scattered to CSR slots in LDS, lane-per-row sums (large E) */
+    CANOPY_KERNEL_FILTER_REFINE = 5 /* cut_off > 0, no per-row output: a fast unordered pass flags the rows
+                                       that might survive, an exact CSR-order pass recomputes only those.
+                                       Reported values are exactly those of the other variants. */
 };
 
 CANOPY_API void canopy_quant_params_default(canopy_quant_params* params);

@@ -25,7 +25,7 @@ def rel(a, b):
     return abs(a - b) / max(abs(b), 1e-300)
 
 
-def variants(n_events, max_row_len=10):
+def variants(n_events, max_row_len=10, cut_off=0.0):
     from canopy_amd import _capi
     v = [_capi.KERNEL_ROWS]
     if n_events <= 12288:
@@ -34,6 +34,8 @@ def variants(n_events, max_row_len=10):
         v.append(_capi.KERNEL_WAVE_STREAM)
     if n_events <= (1 << 18) and max_row_len <= 4095:
         v.append(_capi.KERNEL_VALUE_SCATTER)
+    if 1 <= n_events <= (1 << 18) and cut_off > 0:
+        v.append(_capi.KERNEL_FILTER_REFINE)  # sum-only variant (no per-row output)
     return v
 
 
@@ -44,7 +46,23 @@ def check_against_oracle(ctx, oracle, row_ptr, col, p, n_events, cut_off, limit_
     model = ctx.upload(row_ptr, col, n_events, row_offset=row_offset)
     model.set_probabilities(p)
     max_len = int(np.diff(row_ptr).max()) if len(row_ptr) > 1 else 0
-    for kern in variants(n_events, max_len):
+    for kern in variants(n_events, max_len, cut_off):
+        if kern == _capi.KERNEL_FILTER_REFINE:
+            got = ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order,
+                                                     flags=_capi.QUANT_KEEP_MASK, kernel=kern))
+            assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row), kern
+            if want.n_kept:
+                assert got.max_logp == want.max_logp
+            if len(row_ptr) > 1:
+                assert np.array_equal(ctx.fetch_keep_mask(model), want.keep_mask), kern
+            if math.isfinite(want.rare_event) and want.rare_event > 0:
+                assert rel(got.rare_event, want.rare_event) < TOL and rel(got.mcub, want.mcub) < TOL
+            else:
+                assert got.rare_event == want.rare_event and got.mcub == want.mcub
+            got2 = ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order, kernel=kern))
+            assert (got2.rare_event, got2.mcub, got2.n_kept, got2.argmax_row) == (got.rare_event, got.mcub, got.n_kept,
+                                                                                  got.argmax_row)
+            continue
         prm = default_params(cut_off=cut_off, limit_order=limit_order,
                              flags=_capi.QUANT_ROW_LOGP | _capi.QUANT_KEEP_MASK, kernel=kern)
         got = ctx.quantify(model, prm)
@@ -147,7 +165,7 @@ def test_against_mpmath_golden(gpu_ctx, idx):
     model = gpu_ctx.synthetic(g["seed"], c["n_rows"], g["n_events"], c["avg"], first_row=c["first_row"])
     model.set_probabilities(np.array([float.fromhex(x) for x in g["p_%s_hex" % c["p"]]]))
     e = c["expected"]
-    for kern in variants(g["n_events"]):
+    for kern in variants(g["n_events"], 10, c["cut_off"]):
         r = gpu_ctx.quantify(model, default_params(cut_off=c["cut_off"], limit_order=c["limit_order"], kernel=kern))
         assert r.n_kept == e["n_kept"] and r.argmax_row == e["argmax_row"]
         assert rel(r.rare_event, float(e["rare"])) < 1e-12 and rel(r.mcub, float(e["mcub"])) < 1e-12
@@ -225,6 +243,14 @@ def test_config3_full_size_properties(gpu_ctx, oracle):
     assert both.max_logp == whole.max_logp
     assert rel(both.rare_event, whole.rare_event) < TOL and rel(both.mcub, whole.mcub) < TOL
     assert part_whole.n_kept == whole.n_kept
+
+
+def test_filter_refine_wide_event_space(gpu_ctx, oracle):
+    """E > 2^17 switches the filter/refine stream to 8192-row slabs (14 row bits, 18 column bits)."""
+    n_events = 200000
+    row_ptr, col = oracle.synth_csr(SEED, 300000, n_events, 6, n_threads=4)
+    p = oracle.synth_probabilities(SEED, n_events)
+    check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, 1e-10, 20, threads=4)
 
 
 def test_gather_slot_buffer_single_rank(gpu_ctx, oracle):
