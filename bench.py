@@ -149,6 +149,12 @@ def main():
     else:
         result = canopy_amd.combine_partials([ctx.fetch_partial()])
 
+    auto_fr = args.kernel == 0 and args.cut_off > 0 and 2048 < info.n_events <= (1 << 18)
+    kernel_label = {1: "k_rows (lane per row, L2 gather)", 2: "k_rows (lane per row, LDS table)",
+                    3: "k_ws (wave-slab stream)", 4: "k_vs (value scatter)",
+                    5: "k_fr_filter + k_fr_refine (filter, then exact refine)"}.get(
+        args.kernel, "k_fr_filter + k_fr_refine (filter, then exact refine)" if auto_fr else
+        ("k_ws (wave-slab stream)" if info.n_events > 2048 else "k_rows (lane per row, LDS table)"))
     if rank == 0:
         total_rows = info.n_rows * world
         ms_per_step = elapsed * 1e3 / args.steps
@@ -176,7 +182,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": ("k_ws (wave-slab stream, K1-K4 fused)" if info.stream_bytes else "k_rows (K1-K4 fused)"),
+                "kernel": kernel_label,
                 "algorithmic_bytes_per_launch": info.algorithmic_bytes,
                 "bytes_per_cut_set": info.algorithmic_bytes / max(info.n_rows, 1),
                 "stream_bytes_per_launch": info.stream_bytes, "avg_kernel_ms": k_ms, "avg_pass_ms": tot_ms_sum / max(n_timed, 1), "launches_timed": n_timed,

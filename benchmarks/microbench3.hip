@@ -6,7 +6,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 __device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 
-// MODE 0: random slot; 1: conflict-free (slot mod 32 == lane mod 32, random multiple of 32 on top);
+// MODE 4: ds_add_f32 random slot; MODE 0: random slot; 1: conflict-free (slot mod 32 == lane mod 32, random multiple of 32 on top);
 // 2: like 1 but per 64-lane: slot mod 64 == lane; 3: random slot but read+add+write
 template <int MODE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_add(uint32_t S, int iters, double* out) {
@@ -17,10 +17,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_add(uint32_t S, int iters, doubl
     for (int it = 0; it < iters; ++it) {
         const uint32_t h = hash32((uint32_t)it * 0x85EBCA6BU + blockIdx.x * 77u + threadIdx.x * 0x9E3779B9U);
         uint32_t slot;
-        if (MODE == 0 || MODE == 3) slot = h % S;
+        if (MODE == 0 || MODE == 3 || MODE == 4) slot = h % S;
         else if (MODE == 1) slot = ((h % (S / 32)) * 32) + (lane & 31);
         else slot = ((h % (S / 64)) * 64) + lane;
-        if (MODE == 3) s_sum[slot] += 1.5;
+        if (MODE == 4) __hip_atomic_fetch_add(reinterpret_cast<float*>(s_sum) + slot, 1.5f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        else if (MODE == 3) s_sum[slot] += 1.5;
         else __hip_atomic_fetch_add(&s_sum[slot], 1.5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     __syncthreads();
@@ -47,6 +48,7 @@ int main() {
     run<1, 16>("ds_add_f64 conflict-free/32", n_cu, d_out, e0, e1);
     run<2, 16>("ds_add_f64 conflict-free/64", n_cu, d_out, e0, e1);
     run<3, 16>("rd+add+wr random", n_cu, d_out, e0, e1);
+    run<4, 16>("ds_add_f32 random", n_cu, d_out, e0, e1);
     run<0, 4>("ds_add_f64 random", n_cu, d_out, e0, e1);
     run<1, 4>("ds_add_f64 conflict-free/32", n_cu, d_out, e0, e1);
     run<2, 4>("ds_add_f64 conflict-free/64", n_cu, d_out, e0, e1);
