@@ -71,7 +71,17 @@ __global__ __launch_bounds__(kMcWaves * kWave) void k_mc(McArgs a) {
     for (int64_t w = (int64_t)blockIdx.x * kMcWaves + wave; w < a.n_words; w += GW) {
         const uint64_t n = (uint64_t)(a.first_word + w) * 64u + (uint64_t)lane; // global sample index
         // ---- phase 1: Bernoulli bits of every basic event, 64 samples per ballot
-        for (int j = 0; j < a.n_events; ++j) {
+        int j = 0;
+        for (; j + 4 <= a.n_events; j += 4) { // 4 independent hashes in flight per lane
+            uint64_t h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h[u] = mix64(s_ek[j + u] + n);
+            unsigned long long m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m[u] = __ballot((h[u] >> 11) < s_th[j + u]);
+            if (lane < 4) node[j + lane] = m[0] * (lane == 0) + m[1] * (lane == 1) + m[2] * (lane == 2) + m[3] * (lane == 3);
+        }
+        for (; j < a.n_events; ++j) {
             const uint64_t h = mix64(s_ek[j] + n);
             const unsigned long long m = __ballot((h >> 11) < s_th[j]);
             if (lane == 0) node[j] = m;
