@@ -186,3 +186,20 @@ def test_example_tree_through_the_gpu_paths(gpu_ctx, oracle):
     assert r.hits == oracle.mc(ft.dag(), p, 7, 3_000_000, n_threads=4)
     assert abs(r.estimate - 0.0308655046) < 5 * r.std_error
     d.close()
+
+
+@pytest.mark.gpu
+def test_cpp_example_runs_end_to_end(canopy_lib, tmp_path):
+    """The C++ consumer of include/canopy-cpp.h: built against libcanopy.so, run on the device."""
+    import json
+    import subprocess
+    exe = tmp_path / "quantify_mef"
+    lib_dir = os.path.join(ROOT, "canopy_amd")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "quantify_mef.cpp"), "-L", lib_dir, "-lcanopy",
+                    "-Wl,-rpath," + lib_dir, "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe), EXAMPLE], check=True, capture_output=True, text=True).stdout
+    r = json.loads(out)
+    assert r["cut_sets"] == 6 and r["basic_events"] == 7 and r["top"] == "TOP"
+    assert abs(r["rare_event"] - 0.033) < 1e-15 and abs(r["mcub"] - 0.03260898707329901) < 1e-15
+    assert abs(r["monte_carlo"] - 0.0308655046) < 5 * r["mc_std_error"]
