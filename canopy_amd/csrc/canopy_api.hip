@@ -14,6 +14,11 @@ using namespace canopy;
 
 namespace {
 
+uint64_t next_model_id() {
+    static uint64_t counter = 0;
+    return ++counter;
+}
+
 canopy_status fail(canopy_ctx* ctx, canopy_status st, const std::string& msg) {
     if (ctx) ctx->last_error = msg;
     return st;
@@ -155,6 +160,8 @@ void canopy_ctx_free(canopy_ctx* ctx) {
     if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
     if (ctx->d_row_logp) (void)hipFree(ctx->d_row_logp);
     if (ctx->d_keep_mask) (void)hipFree(ctx->d_keep_mask);
+    if (ctx->d_fr_count) (void)hipFree(ctx->d_fr_count);
+    if (ctx->h_fr_count) (void)hipHostFree(ctx->h_fr_count);
     if (ctx->d_mc_hits) (void)hipFree(ctx->d_mc_hits);
     if (ctx->h_mc_hits) (void)hipHostFree(ctx->h_mc_hits);
     for (auto ev : ctx->ev_mc) if (ev) (void)hipEventDestroy(ev);
@@ -206,6 +213,7 @@ canopy_status canopy_model_upload(canopy_ctx* ctx, const canopy_csr_view* csr, u
 
     canopy_model* m = new (std::nothrow) canopy_model();
     if (!m) return CANOPY_ERR_OUT_OF_MEMORY;
+    m->id = next_model_id();
     m->device = ctx->device;
     m->n_rows = csr->n_rows; m->n_events = csr->n_events; m->nnz = nnz; m->row_offset = csr->row_offset;
     canopy_status st = CANOPY_OK;
@@ -270,6 +278,7 @@ canopy_status canopy_model_synthetic(canopy_ctx* ctx, uint64_t seed, int64_t fir
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     canopy_model* m = new (std::nothrow) canopy_model();
     if (!m) return CANOPY_ERR_OUT_OF_MEMORY;
+    m->id = next_model_id();
     m->device = ctx->device;
     m->n_rows = n_rows; m->n_events = n_events; m->row_offset = first_row;
     m->max_row_len = 2 * avg_nnz - 2;
@@ -431,7 +440,8 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     int variant = params->kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : params->kernel;
     // AUTO: with a positive cut-off and no per-row output, filter/refine replaces the wave-slab stream
     if (params->kernel == CANOPY_KERNEL_AUTO && variant == CANOPY_KERNEL_WAVE_STREAM && params->cut_off > 0.0 &&
-        !want_rows_early && m->n_events <= fr_max_events()) {
+        !want_rows_early && m->n_events <= fr_max_events() &&
+        !(ctx->fr_known_id == m->id && ctx->fr_known_fraction > 0.2)) { // the filter flagged > 20 % last time: not worth it
         canopy_status pst = build_fr(ctx, const_cast<canopy_model*>(m));
         if (pst != CANOPY_OK) return pst;
         if (m->fr_state == 1) variant = CANOPY_KERNEL_FILTER_REFINE;
@@ -519,8 +529,16 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     if (variant == CANOPY_KERNEL_FILTER_REFINE) {
         // delta covers the rounding difference between the unordered pass-A sum and the CSR-order sum
         const double cand_cut = a.log_cut - (1e-9 + 1e-11 * (double)m->max_row_len);
+        if (!ctx->d_fr_count) {
+            HIP_TRY(ctx, hipMalloc(&ctx->d_fr_count, sizeof(unsigned long long)));
+            HIP_TRY(ctx, hipHostMalloc(&ctx->h_fr_count, sizeof(unsigned long long)));
+        }
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_fr_count, 0, sizeof(unsigned long long), ctx->stream));
+        ctx->fr_pending_id = m->id;
+        ctx->fr_pending_rows = m->n_rows;
         HIP_TRY(ctx, launch_fr_filter(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, m->n_rows,
-                                      m->n_events, m->n_fr_slabs, cand_cut, ctx->d_keep_mask, ctx->n_cu, ctx->stream));
+                                      m->n_events, m->n_fr_slabs, cand_cut, ctx->d_keep_mask, ctx->d_fr_count, ctx->n_cu,
+                                      ctx->stream));
         HIP_TRY(ctx, launch_fr_refine(a, ctx->d_keep_mask, n_words, want_mask ? 1 : 0, grid, ctx->stream));
     } else if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
         HIP_TRY(ctx, launch_vs_kernel(a, m->d_vs_stream, m->d_vs_off, m->d_vs_slab_row, m->vs_total_chunks, m->n_slabs,
@@ -547,8 +565,16 @@ canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* out) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, ctx->d_partial, sizeof(double) * CANOPY_PARTIAL_DOUBLES,
                                 hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->fr_pending_id)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fr_count, ctx->d_fr_count, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                    ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out, ctx->h_partial, sizeof(canopy_partial));
+    if (ctx->fr_pending_id) { // feedback for AUTO: a filter that flags most rows is not worth its refine pass
+        ctx->fr_known_id = ctx->fr_pending_id;
+        ctx->fr_known_fraction = ctx->fr_pending_rows > 0 ? (double)*ctx->h_fr_count / (double)ctx->fr_pending_rows : 0.0;
+        ctx->fr_pending_id = 0;
+    }
     return CANOPY_OK;
 }
 

@@ -37,6 +37,13 @@ struct canopy_ctx {
     int timing_max = 0, timing_n = 0;
     bool timing_on = false;
 
+    // FILTER_REFINE: candidates flagged by the last filter pass (device counter, pinned mirror)
+    unsigned long long* d_fr_count = nullptr;
+    unsigned long long* h_fr_count = nullptr;
+    uint64_t fr_pending_id = 0;   // model id whose filter count is still on the device (0 = none)
+    int64_t fr_pending_rows = 0;
+    uint64_t fr_known_id = 0;     // last model id with a known candidate fraction
+    double fr_known_fraction = -1.0;
     // K6 Monte-Carlo
     unsigned long long* d_mc_hits = nullptr; // [1]
     unsigned long long* h_mc_hits = nullptr; // pinned
@@ -60,6 +67,7 @@ struct canopy_dag {
 };
 
 struct canopy_model {
+    uint64_t id = 0; // unique per process (never reused): contexts refer to models by id, not by pointer
     int device = 0;
     int64_t n_rows = 0, nnz = 0, row_offset = 0;
     int32_t n_events = 0, max_row_len = 0;
@@ -151,7 +159,7 @@ hipError_t fr_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
                     int64_t* n_slabs_out, bool* ok, hipStream_t s);
 hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
                             int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint64_t* cand_mask,
-                            int n_cu, hipStream_t s);
+                            unsigned long long* cand_count, int n_cu, hipStream_t s);
 hipError_t launch_fr_refine(const RowKernelArgs& a, uint64_t* mask, int64_t n_words, int write_mask, int grid,
                             hipStream_t s);
 

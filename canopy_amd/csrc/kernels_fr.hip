@@ -123,7 +123,8 @@ __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const u
                                                              const int64_t* __restrict__ fr_off, int64_t total_chunks,
                                                              const double* __restrict__ logp, int64_t n_rows,
                                                              int64_t n_slabs, double cand_cut,
-                                                             uint64_t* __restrict__ cand_mask) {
+                                                             uint64_t* __restrict__ cand_mask,
+                                                             unsigned long long* __restrict__ cand_count) {
     using Cf = FrCfg<SLAB_ROWS>;
     constexpr int kFrRowBits = Cf::row_bits, kFrSlabRows = Cf::slab_rows, kFrSlots = Cf::slots, kFrWaves = Cf::waves,
                   kFrThreads = Cf::threads;
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const u
     for (int i = tid; i < kFrSlots; i += kFrThreads) sums[i] = 0.0;
     fr_barrier();
 
+    unsigned long long n_cand = 0; // counted by lane 0 of each wave
     const int64_t G = (int64_t)gridDim.x;
     for (int64_t s = (int64_t)blockIdx.x; s < n_slabs; s += G) {
         const int64_t c0 = fr_uload(fr_off + s), c1 = fr_uload(fr_off + s + 1);
@@ -181,10 +183,12 @@ __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const u
             const int64_t r = r0 + rl;
             const unsigned long long m = __ballot(r < n_rows && sv >= cand_cut);
             if (lane == 0 && r < n_rows) cand_mask[r >> 6] = m;
+            n_cand += (unsigned long long)__builtin_popcountll(m);
         }
         if (tid < 64) sums[kFrSlabRows + tid] = 0.0; // the sink
         fr_barrier();
     }
+    if (lane == 0 && n_cand) atomicAdd(cand_count, n_cand); // lets the host see when the filter stops paying off
 }
 
 // ---- pass B ------------------------------------------------------------------------------------------
@@ -339,8 +343,8 @@ hipError_t fr_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
 namespace {
 template <int SLAB_ROWS, int U>
 hipError_t launch_fr_filter_t(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
-                              int64_t n_rows, int64_t n_slabs, double cand_cut, uint64_t* cand_mask, int n_cu,
-                              hipStream_t s) {
+                              int64_t n_rows, int64_t n_slabs, double cand_cut, uint64_t* cand_mask,
+                              unsigned long long* cand_count, int n_cu, hipStream_t s) {
     using Cf = FrCfg<SLAB_ROWS>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -354,25 +358,25 @@ hipError_t launch_fr_filter_t(const uint32_t* stream, const int64_t* fr_off, int
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL((k_fr_filter<SLAB_ROWS, U>), dim3((unsigned)grid), dim3(Cf::threads), Cf::lds, s,
                        reinterpret_cast<const uint4*>(stream), fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut,
-                       cand_mask);
+                       cand_mask, cand_count);
     return hipGetLastError();
 }
 } // namespace
 
 hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
                             int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint64_t* cand_mask,
-                            int n_cu, hipStream_t s) {
+                            unsigned long long* cand_count, int n_cu, hipStream_t s) {
     static const int u = getenv("CANOPY_FR_U") ? atoi(getenv("CANOPY_FR_U")) : 4; // tuning only
     if (fr_slab_rows_for(n_events) == 16384) {
-        if (u == 1) return launch_fr_filter_t<16384, 1>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
-        if (u == 4) return launch_fr_filter_t<16384, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
-        if (u == 2) return launch_fr_filter_t<16384, 2>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
-        return launch_fr_filter_t<16384, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
+        if (u == 1) return launch_fr_filter_t<16384, 1>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
+        if (u == 4) return launch_fr_filter_t<16384, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
+        if (u == 2) return launch_fr_filter_t<16384, 2>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
+        return launch_fr_filter_t<16384, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
     }
-    if (u == 1) return launch_fr_filter_t<8192, 1>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
-    if (u == 4) return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
-    if (u == 2) return launch_fr_filter_t<8192, 2>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
-    return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, n_cu, s);
+    if (u == 1) return launch_fr_filter_t<8192, 1>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
+    if (u == 4) return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
+    if (u == 2) return launch_fr_filter_t<8192, 2>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
+    return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
 }
 
 hipError_t launch_fr_refine(const RowKernelArgs& a, uint64_t* mask, int64_t n_words, int write_mask, int grid,

@@ -277,3 +277,24 @@ def test_gather_slot_buffer_single_rank(gpu_ctx, oracle):
     o = oracle.quantify(row_ptr, col, p, cut_off=1e-9, row_offset=777)
     assert got.n_kept == int(o.n_kept) and got.argmax_row == int(o.argmax_row)
     model.close()
+
+
+def test_auto_leaves_filter_refine_when_most_rows_survive(gpu_ctx, oracle):
+    """AUTO feedback: with a cut-off that keeps most rows the filter flags > 20 % of them; the next AUTO
+    pass on that model runs the wave-slab stream instead. Results are the oracle's either way."""
+    from canopy_amd import default_params
+    n_events = 5000
+    row_ptr, col = oracle.synth_csr(SEED, 200000, n_events, 4, n_threads=4)
+    p = oracle.synth_probabilities(SEED, n_events)
+    want = oracle.quantify(row_ptr, col, p, cut_off=1e-30, limit_order=20)
+    assert want.n_kept > 0.5 * 200000
+    model = gpu_ctx.upload(row_ptr, col, n_events)
+    model.set_probabilities(p)
+    times = []
+    for _ in range(3):
+        got = gpu_ctx.quantify(model, default_params(cut_off=1e-30))
+        assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row)
+        assert rel(got.rare_event, want.rare_event) < TOL and rel(got.mcub, want.mcub) < TOL
+        times.append(got.elapsed_kernel_ms)
+    assert times[1] < times[0]  # first call: filter + a refine pass over nearly every row; then WAVE_STREAM
+    model.close()
