@@ -57,6 +57,8 @@ void free_model_buffers(canopy_model* m) {
     if (m->d_row_ptr) (void)hipFree(m->d_row_ptr);
     if (m->d_col_idx) (void)hipFree(m->d_col_idx);
     if (m->d_logp) (void)hipFree(m->d_logp);
+    if (m->d_q8) (void)hipFree(m->d_q8);
+    m->d_q8 = nullptr;
     if (m->d_ws_stream) (void)hipFree(m->d_ws_stream);
     if (m->d_ws_off) (void)hipFree(m->d_ws_off);
     if (m->d_vs_stream) (void)hipFree(m->d_vs_stream);
@@ -536,6 +538,13 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_fr_count, 0, sizeof(unsigned long long), ctx->stream));
         ctx->fr_pending_id = m->id;
         ctx->fr_pending_rows = m->n_rows;
+        if (fr_filter_is_quantised(m->n_events)) {
+            canopy_model* mm = const_cast<canopy_model*>(m);
+            if (!mm->d_q8) HIP_TRY(ctx, hipMalloc(&mm->d_q8, (((size_t)m->n_events + 15) / 16) * 16 + 16));
+            HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, mm->d_q8, m->n_rows,
+                                             m->n_events, m->n_fr_slabs, a.log_cut, ctx->d_keep_mask, ctx->d_fr_count,
+                                             ctx->n_cu, ctx->stream));
+        } else
         HIP_TRY(ctx, launch_fr_filter(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, m->n_rows,
                                       m->n_events, m->n_fr_slabs, cand_cut, ctx->d_keep_mask, ctx->d_fr_count, ctx->n_cu,
                                       ctx->stream));

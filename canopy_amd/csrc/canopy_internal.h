@@ -74,6 +74,7 @@ struct canopy_model {
     int64_t* d_row_ptr = nullptr; // [n_rows+1], rebased to 0
     int32_t* d_col_idx = nullptr; // [nnz] (+ 16 B of slack for 16-byte slab loads)
     double* d_logp = nullptr;     // [n_events]
+    uint8_t* d_q8 = nullptr;      // [n_events rounded up to 16] quantised -logp of the FILTER_REFINE filter pass
     bool has_p = false;
     int64_t device_bytes = 0;
     // derived wave-slab stream layout (kernels_ws.hip), built by canopy_model_prepare
@@ -160,6 +161,10 @@ hipError_t fr_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
 hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
                             int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint64_t* cand_mask,
                             unsigned long long* cand_count, int n_cu, hipStream_t s);
+bool fr_filter_is_quantised(int32_t n_events);
+hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
+                               uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs, double log_cut,
+                               uint64_t* cand_mask, unsigned long long* cand_count, int n_cu, hipStream_t s);
 hipError_t launch_fr_refine(const RowKernelArgs& a, uint64_t* mask, int64_t n_words, int write_mask, int grid,
                             hipStream_t s);
 

@@ -50,9 +50,18 @@ struct FrCfg {
 
 // 16384-row slabs (one 16-wave workgroup per CU) measured faster than 8192-row slabs (two 8-wave
 // workgroups): 0.85 vs 0.98 ms at config 3. They need 15 row bits, i.e. E <= 2^17; beyond that 8192.
+constexpr int kQ8MaxEvents = 112 * 1024; // 8-bit table + 8192 u32 row sums must fit the 160 KiB of LDS
+constexpr int kQ8Levels = 224;           // threshold level; entries clamp at 255 (alone enough to kill a row)
+
+bool fr_use_q8(int32_t n_events) {
+    static const bool off = getenv("CANOPY_FR_NOQ8") != nullptr; // tuning only
+    return !off && n_events <= kQ8MaxEvents;
+}
+
 int fr_slab_rows_for(int32_t n_events) {
     static const int forced = getenv("CANOPY_FR_SLAB") ? atoi(getenv("CANOPY_FR_SLAB")) : 0; // tuning only
     if (forced == 8192 || forced == 16384) return forced;
+    if (fr_use_q8(n_events)) return 8192; // quantised LDS-table filter: 8192-row slabs
     return n_events <= (1 << 17) ? 16384 : 8192;
 }
 
@@ -191,6 +200,99 @@ __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const u
     if (lane == 0 && n_cand) atomicAdd(cand_count, n_cand); // lets the host see when the filter stops paying off
 }
 
+// ---- pass A, quantised form ---------------------------------------------------------------------------
+// The filter only has to be CONSERVATIVE, not precise: q_j = floor(-logp_j / step) (clamped to 255) is a
+// lower bound of -logp_j in units of `step`, so step * sum(q) <= -s_i and
+//     s_i >= log(cut_off)   ==>   sum(q) <= T = floor(-log(cut_off) / step).
+// With step = -log(cut_off) / 224 one byte per basic event suffices and the whole table (E <= 112 K) sits
+// in LDS beside 8192 u32 row sums: the filter pass issues NO texture-path gathers (the path that bounds
+// the fp64 filter at ~33 clk per 64 lanes), only ds_read_u8 + ds_add_u32, and the TA just streams.
+// The price is a looser bound (about 0.08 per entry in log units): more candidates for the exact pass B.
+__global__ __launch_bounds__(256) void k_fr_q8_table(const double* __restrict__ logp, int32_t n_events, double inv_step,
+                                                     uint8_t* __restrict__ q8) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_events) return;
+    const double neg = -logp[j]; // >= 0, +inf for p = 0
+    // (1 - 2^-30): the bound must stay a lower bound although (a) the product may round up across an
+    // integer and (b) the CSR-order fp64 sum s_i differs from the exact sum by up to len * 2^-53 relative
+    // (2^-30 covers rows of up to 2^22 entries)
+    const double lv = neg * inv_step * (1.0 - 0x1.0p-30);
+    q8[j] = (uint8_t)(lv >= 255.0 ? 255 : (int)lv);
+}
+
+constexpr int kQ8SlabRows = 8192, kQ8RowBits = 14, kQ8Waves = 16, kQ8Threads = kQ8Waves * kWave;
+constexpr uint32_t kQ8RowMask = (1u << kQ8RowBits) - 1;
+constexpr size_t kQ8SumsBytes = (size_t)(kQ8SlabRows + 64) * 4;
+
+template <int U>
+__global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __restrict__ stream,
+                                                             const int64_t* __restrict__ fr_off, int64_t total_chunks,
+                                                             const uint8_t* __restrict__ q8, int32_t n_events,
+                                                             int64_t n_rows, int64_t n_slabs, int threshold,
+                                                             uint64_t* __restrict__ cand_mask,
+                                                             unsigned long long* __restrict__ cand_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* sums = reinterpret_cast<unsigned*>(smem);
+    uint8_t* tab = reinterpret_cast<uint8_t*>(smem + kQ8SumsBytes);
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    for (int i = tid; i < kQ8SlabRows + 64; i += kQ8Threads) sums[i] = 0u;
+    { // the table, 16 bytes per lane per step (its buffer is padded to a multiple of 16)
+        const uint4* src = reinterpret_cast<const uint4*>(q8);
+        uint4* dst = reinterpret_cast<uint4*>(tab);
+        for (int i = tid; i < (n_events + 15) / 16; i += kQ8Threads) dst[i] = src[i];
+    }
+    fr_barrier();
+
+    unsigned long long n_cand = 0;
+    const int64_t G = (int64_t)gridDim.x;
+    for (int64_t s = (int64_t)blockIdx.x; s < n_slabs; s += G) {
+        const int64_t c0 = fr_uload(fr_off + s), c1 = fr_uload(fr_off + s + 1);
+        uint4 q[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = c0 + wave + (int64_t)u * kQ8Waves;
+            q[u] = stream[(c < c1 ? c : total_chunks) * kWave + lane];
+        }
+        for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * kQ8Waves) {
+            uint4 qn[U]; // next step's chunks first: nothing else is in the vector-memory queue
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t c = cb + (int64_t)(U + u) * kQ8Waves;
+                qn[u] = stream[(c < c1 ? c : total_chunks) * kWave + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                unsigned v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = tab[e[k] >> kQ8RowBits];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    __hip_atomic_fetch_add(&sums[e[k] & kQ8RowMask], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) q[u] = qn[u];
+        }
+        fr_barrier();
+        const int64_t r0 = s * kQ8SlabRows;
+#pragma unroll 4
+        for (int i = 0; i < kQ8SlabRows / kQ8Threads; ++i) {
+            const int rl = i * kQ8Threads + tid;
+            const int sv = (int)sums[rl];
+            sums[rl] = 0u;
+            const int64_t r = r0 + rl;
+            const unsigned long long m = __ballot(r < n_rows && sv <= threshold);
+            if (lane == 0 && r < n_rows) cand_mask[r >> 6] = m;
+            n_cand += (unsigned long long)__builtin_popcountll(m);
+        }
+        if (tid < 64) sums[kQ8SlabRows + tid] = 0u; // the sink
+        fr_barrier();
+    }
+    if (lane == 0 && n_cand) atomicAdd(cand_count, n_cand);
+}
+
 // ---- pass B ------------------------------------------------------------------------------------------
 // One lane per mask word (64 rows): the lane walks the word's candidate bits; each candidate row is
 // summed from the canonical CSR in CSR order. Fixed lane <- word assignment => reproducible.
@@ -254,6 +356,7 @@ __global__ __launch_bounds__(256) void k_fr_refine(RowKernelArgs a, uint64_t* __
 } // namespace
 
 int fr_max_events() { return 1 << 18; }
+bool fr_filter_is_quantised(int32_t n_events) { return fr_use_q8(n_events) && fr_slab_rows_for(n_events) == 8192; }
 int fr_refine_grid(int n_cu) { return n_cu * 8; }
 
 hipError_t fr_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events,
@@ -377,6 +480,38 @@ hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64
     if (u == 4) return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
     if (u == 2) return launch_fr_filter_t<8192, 2>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
     return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
+}
+
+// Quantised filter: builds the 8-bit table for (logp, cut-off) and runs k_fr_filter_q8. q8_buf holds
+// n_events bytes rounded up to 16.
+hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
+                               uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs, double log_cut,
+                               uint64_t* cand_mask, unsigned long long* cand_count, int n_cu, hipStream_t s) {
+    const double mag = -log_cut > 1.0 ? -log_cut : 1.0;
+    const double inv_step = (double)kQ8Levels / mag;
+    // s >= log_cut  ==>  sum(q) <= -log_cut / step; (1 + 2^-28): a hair generous, never too strict
+    const double t = -log_cut * inv_step * (1.0 + 0x1.0p-28);
+    const int threshold = t < 0.0 ? -1 : (t > 2.0e9 ? 2000000000 : (int)t);
+    hipLaunchKernelGGL(k_fr_q8_table, dim3(grid_for(n_events, 256)), dim3(256), 0, s, logp, n_events, inv_step, q8_buf);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    static const int u = getenv("CANOPY_FR_QU") ? atoi(getenv("CANOPY_FR_QU")) : 2; // tuning only
+    const size_t lds = kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int64_t grid = n_cu;
+    if (grid > n_slabs) grid = n_slabs;
+    if (grid < 1) grid = 1;
+#define Q8_GO(UU) hipLaunchKernelGGL(k_fr_filter_q8<UU>, dim3((unsigned)grid), dim3(kQ8Threads), lds, s, reinterpret_cast<const uint4*>(stream), fr_off, total_chunks, q8_buf, n_events, n_rows, n_slabs, threshold, cand_mask, cand_count)
+    if (u == 1) Q8_GO(1); else if (u == 4) Q8_GO(4); else Q8_GO(2);
+#undef Q8_GO
+    return hipGetLastError();
 }
 
 hipError_t launch_fr_refine(const RowKernelArgs& a, uint64_t* mask, int64_t n_words, int write_mask, int grid,
