@@ -535,7 +535,8 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             HIP_TRY(ctx, hipMalloc(&ctx->d_fr_count, sizeof(unsigned long long)));
             HIP_TRY(ctx, hipHostMalloc(&ctx->h_fr_count, sizeof(unsigned long long)));
         }
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_fr_count, 0, sizeof(unsigned long long), ctx->stream));
+        if (!fr_filter_is_quantised(m->n_events)) // (the quantised path clears the counter in its table kernel)
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_fr_count, 0, sizeof(unsigned long long), ctx->stream));
         ctx->fr_pending_id = m->id;
         ctx->fr_pending_rows = m->n_rows;
         if (fr_filter_is_quantised(m->n_events)) {

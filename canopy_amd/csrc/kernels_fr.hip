@@ -209,8 +209,9 @@ __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const u
 // the fp64 filter at ~33 clk per 64 lanes), only ds_read_u8 + ds_add_u32, and the TA just streams.
 // The price is a looser bound (about 0.08 per entry in log units): more candidates for the exact pass B.
 __global__ __launch_bounds__(256) void k_fr_q8_table(const double* __restrict__ logp, int32_t n_events, double inv_step,
-                                                     uint8_t* __restrict__ q8) {
+                                                     uint8_t* __restrict__ q8, unsigned long long* cand_count) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) *cand_count = 0ULL; // the filter kernel behind this one counts its candidates here
     if (j >= n_events) return;
     const double neg = -logp[j]; // >= 0, +inf for p = 0
     // (1 - 2^-30): the bound must stay a lower bound although (a) the product may round up across an
@@ -294,49 +295,97 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
 }
 
 // ---- pass B ------------------------------------------------------------------------------------------
-// One lane per mask word (64 rows): the lane walks the word's candidate bits; each candidate row is
-// summed from the canonical CSR in CSR order. Fixed lane <- word assignment => reproducible.
-__global__ __launch_bounds__(256) void k_fr_refine(RowKernelArgs a, uint64_t* __restrict__ mask /* in: candidates, out: keep */,
-                                                   int64_t n_words, int write_mask) {
-    __shared__ double s_red[4 * kAccDoubles];
+// A wave takes 64 consecutive mask words (4096 rows), compacts their candidate bits into an LDS list
+// (wave-level prefix sum of the popcounts) and recomputes the candidates 64 at a time: each lane sums one
+// candidate row from the canonical CSR in CSR order. Fixed wave <- words and lane <- candidate
+// assignment => reproducible. Exact keep bits are collected per word in LDS and written back in place.
+constexpr int kRefineWaves = 4;
+constexpr int kRefineCap = 1024; // candidates a wave can compact per 4096 rows; beyond that: per-lane walk
+
+__device__ __forceinline__ double refine_row_sum(const RowKernelArgs& a, int64_t r, int* len_out) {
+    const int64_t b = a.row_ptr[r], e = a.row_ptr[r + 1];
+    double s = 0.0;
+    // 8 entries at a time: all column loads, then all table loads, then the adds in CSR order
+    for (int64_t k0 = b; k0 < e; k0 += 8) {
+        int32_t c[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = (k0 + u < e) ? a.col_idx[k0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = a.logp[c[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k0 + u < e) s = s + v[u]; // plain adds, CSR order
+    }
+    *len_out = (int)(e - b);
+    return s;
+}
+
+__global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArgs a, uint64_t* __restrict__ mask /* in: candidates, out: keep */,
+                                                                   int64_t n_words, int write_mask) {
+    __shared__ double s_red[kRefineWaves * kAccDoubles];
+    __shared__ unsigned short s_list[kRefineWaves][kRefineCap];
+    __shared__ unsigned long long s_keep[kRefineWaves][kWave];
     const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    unsigned short* list = s_list[wave];
+    unsigned long long* keepw = s_keep[wave];
     Acc acc;
     acc_init(acc);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + tid; w < n_words; w += stride) {
-        unsigned long long m = mask[w];
-        unsigned long long keep_bits = 0ULL;
-        while (m != 0ULL) {
-            const int bit = __builtin_ctzll(m);
-            m &= m - 1;
-            const int64_t r = w * 64 + bit;
-            const int64_t b = a.row_ptr[r], e = a.row_ptr[r + 1];
-            double s = 0.0;
-            // 8 entries at a time: all column loads, then all table loads, then the adds in CSR order
-            // (three dependent latencies per batch instead of two per entry)
-            for (int64_t k0 = b; k0 < e; k0 += 8) {
-                int32_t c[8];
-                double v[8];
+    const int64_t GW = (int64_t)gridDim.x * kRefineWaves;
+    for (int64_t w0 = ((int64_t)blockIdx.x * kRefineWaves + wave) * kWave; w0 < n_words; w0 += GW * kWave) {
+        const int64_t w = w0 + lane;
+        const unsigned long long m = w < n_words ? mask[w] : 0ULL;
+        // inclusive wave scan of the candidate counts
+        const int cnt = __builtin_popcountll(m);
+        int incl = cnt;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) c[u] = (k0 + u < e) ? a.col_idx[k0 + u] : 0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = a.logp[c[u]];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) if (k0 + u < e) s = s + v[u]; // plain adds, CSR order
-            }
-            const int len = (int)(e - b);
-            const bool keep = (s >= a.log_cut) && (a.limit_order == 0 || len <= a.limit_order);
-            if (keep) {
-                keep_bits |= 1ULL << bit;
-                const double P = exp(s);
-                csum_add(acc.rare, P);
-                if (P < 1.0) csum_add(acc.l1p, log1p(-P)); else acc.n_certain += 1.0;
-                acc.n_kept += 1.0;
-                if (s > acc.max_logp) { acc.max_logp = s; acc.argmax = (double)(a.row_offset + r); }
-            }
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int o = __shfl_up(incl, d, kWave);
+            if (lane >= d) incl += o;
         }
-        if (write_mask) mask[w] = keep_bits;
+        const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
+        if (total == 0) continue; // mask words are already zero
+        if (total <= kRefineCap) {
+            int k = incl - cnt;
+            for (unsigned long long mm = m; mm != 0ULL; mm &= mm - 1)
+                list[k++] = (unsigned short)(lane * 64 + __builtin_ctzll(mm));
+            keepw[lane] = 0ULL;
+            for (int j0 = 0; j0 < total; j0 += kWave) {
+                const bool on = j0 + lane < total;
+                const int ro = on ? (int)list[j0 + lane] : 0;
+                const int64_t r = w0 * 64 + ro;
+                int len = 0;
+                const double s = on ? refine_row_sum(a, r, &len) : 0.0;
+                const bool keep = on && (s >= a.log_cut) && (a.limit_order == 0 || len <= a.limit_order);
+                fold_kept_row(acc.rare, acc.l1p, acc.n_certain, s, keep);
+                if (keep) {
+                    acc.n_kept += 1.0;
+                    // rows arrive in ascending order per lane, ties resolve to the lower row in acc_merge
+                    if (s > acc.max_logp) { acc.max_logp = s; acc.argmax = (double)(a.row_offset + r); }
+                    if (write_mask) atomicOr(&keepw[ro >> 6], 1ULL << (ro & 63));
+                }
+            }
+            if (write_mask && w < n_words) mask[w] = keepw[lane];
+        } else { // a dense window: each lane walks its own word
+            unsigned long long keep_bits = 0ULL;
+            for (unsigned long long mm = m; mm != 0ULL; mm &= mm - 1) {
+                const int bit = __builtin_ctzll(mm);
+                const int64_t r = w * 64 + bit;
+                int len = 0;
+                const double s = refine_row_sum(a, r, &len);
+                const bool keep = (s >= a.log_cut) && (a.limit_order == 0 || len <= a.limit_order);
+                if (keep) {
+                    keep_bits |= 1ULL << bit;
+                    const double P = exp(s);
+                    csum_add(acc.rare, P);
+                    if (P < 1.0) csum_add(acc.l1p, log1p(-P)); else acc.n_certain += 1.0;
+                    acc.n_kept += 1.0;
+                    if (s > acc.max_logp) { acc.max_logp = s; acc.argmax = (double)(a.row_offset + r); }
+                }
+            }
+            if (write_mask && w < n_words) mask[w] = keep_bits;
+        }
     }
     acc_wave_reduce(acc);
     if (lane == 0) acc_store(s_red + wave * kAccDoubles, acc);
@@ -344,7 +393,7 @@ __global__ __launch_bounds__(256) void k_fr_refine(RowKernelArgs a, uint64_t* __
     if (tid == 0) {
         Acc t;
         acc_load(t, s_red);
-        for (int k = 1; k < 4; ++k) {
+        for (int k = 1; k < kRefineWaves; ++k) {
             Acc o;
             acc_load(o, s_red + k * kAccDoubles);
             acc_merge(t, o);
@@ -492,7 +541,7 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
     // s >= log_cut  ==>  sum(q) <= -log_cut / step; (1 + 2^-28): a hair generous, never too strict
     const double t = -log_cut * inv_step * (1.0 + 0x1.0p-28);
     const int threshold = t < 0.0 ? -1 : (t > 2.0e9 ? 2000000000 : (int)t);
-    hipLaunchKernelGGL(k_fr_q8_table, dim3(grid_for(n_events, 256)), dim3(256), 0, s, logp, n_events, inv_step, q8_buf);
+    hipLaunchKernelGGL(k_fr_q8_table, dim3(grid_for(n_events, 256)), dim3(256), 0, s, logp, n_events, inv_step, q8_buf, cand_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     static const int u = getenv("CANOPY_FR_QU") ? atoi(getenv("CANOPY_FR_QU")) : 2; // tuning only
