@@ -149,7 +149,8 @@ def main():
     else:
         result = canopy_amd.combine_partials([ctx.fetch_partial()])
 
-    auto_fr = args.kernel == 0 and args.cut_off > 0 and 2048 < info.n_events <= (1 << 18)
+    auto_fr = (args.kernel == 0 and args.cut_off > 0 and info.n_events <= (1 << 18)
+               and info.n_rows >= (8_000_000 if info.n_events <= 2048 else 1_000_000))
     kernel_label = {1: "k_rows (lane per row, L2 gather)", 2: "k_rows (lane per row, LDS table)",
                     3: "k_ws (wave-slab stream)", 4: "k_vs (value scatter)",
                     5: "k_fr_filter + k_fr_refine (filter, then exact refine)"}.get(

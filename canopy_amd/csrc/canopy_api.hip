@@ -399,6 +399,11 @@ extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, 
     if (m->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "model lives on another device");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int variant = kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : kernel;
+    if (kernel == CANOPY_KERNEL_AUTO && m->n_events >= 1 && m->n_events <= fr_max_events() &&
+        m->n_rows >= (variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)8000000 : (int64_t)1000000)) {
+        canopy_status fst = build_fr(ctx, m); // AUTO may pick filter/refine for cut_off > 0
+        if (fst != CANOPY_OK) return fst;
+    }
     if (variant == CANOPY_KERNEL_ROWS || variant == CANOPY_KERNEL_ROWS_LDS) return CANOPY_OK;
     if (variant == CANOPY_KERNEL_FILTER_REFINE) {
         canopy_status st = build_fr(ctx, m);
@@ -419,10 +424,6 @@ extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, 
     if (st != CANOPY_OK) return st;
     if (m->ws_state != 1 && kernel == CANOPY_KERNEL_WAVE_STREAM)
         return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a wave-slab stream");
-    if (kernel == CANOPY_KERNEL_AUTO && m->n_events <= fr_max_events()) { // AUTO may pick FR for cut_off > 0
-        st = build_fr(ctx, m);
-        if (st != CANOPY_OK) return st;
-    }
     return CANOPY_OK;
 }
 
@@ -440,10 +441,15 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
 
     const bool want_rows_early = (params->flags & CANOPY_QUANT_ROW_LOGP) != 0;
     int variant = params->kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : params->kernel;
-    // AUTO: with a positive cut-off and no per-row output, filter/refine replaces the wave-slab stream
-    if (params->kernel == CANOPY_KERNEL_AUTO && variant == CANOPY_KERNEL_WAVE_STREAM && params->cut_off > 0.0 &&
-        !want_rows_early && m->n_events <= fr_max_events() &&
-        !(ctx->fr_known_id == m->id && ctx->fr_known_fraction > 0.2)) { // the filter flagged > 20 % last time: not worth it
+    // AUTO: with a positive cut-off and no per-row output, filter/refine replaces the row kernels once the
+    // model is large enough to amortise its four launches (measured crossovers: ~8e6 rows against the
+    // LDS-table row kernel, ~1e6 rows against the wave-slab stream), unless its filter flagged > 20 % of
+    // the rows last time.
+    if (params->kernel == CANOPY_KERNEL_AUTO && params->cut_off > 0.0 && !want_rows_early &&
+        m->n_events >= 1 && m->n_events <= fr_max_events() &&
+        m->n_rows >= (variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)8000000 : (int64_t)1000000) &&
+        (variant == CANOPY_KERNEL_WAVE_STREAM || variant == CANOPY_KERNEL_ROWS_LDS) &&
+        !(ctx->fr_known_id == m->id && ctx->fr_known_fraction > 0.2)) {
         canopy_status pst = build_fr(ctx, const_cast<canopy_model*>(m));
         if (pst != CANOPY_OK) return pst;
         if (m->fr_state == 1) variant = CANOPY_KERNEL_FILTER_REFINE;
