@@ -298,3 +298,37 @@ def test_auto_leaves_filter_refine_when_most_rows_survive(gpu_ctx, oracle):
         times.append(got.elapsed_kernel_ms)
     assert times[1] < times[0]  # first call: filter + a refine pass over nearly every row; then WAVE_STREAM
     model.close()
+
+
+def test_filter_refine_rows_on_the_cut_off_boundary(gpu_ctx, oracle):
+    """Adversarial for the conservative filter: the cut-off is placed exactly ON some rows' s_i (and one
+    ulp around it), with rows of 1..40 entries and probabilities spanning 1e-300..1. A filter that is not
+    strictly conservative would lose survivors here; count, argmax and the keep mask must match the oracle."""
+    from canopy_amd import _capi, default_params
+    rng = np.random.default_rng(11)
+    n_events, n_rows = 3000, 60000
+    p = 10.0 ** rng.uniform(-6, 0, size=n_events)
+    p[:5] = [1.0, 1e-300, 1e-12, 0.5, 0.0]
+    rows = []
+    for i in range(n_rows):
+        ln = int(rng.integers(1, 41)) if i % 7 else int(rng.integers(1, 4))
+        rows.append(np.sort(rng.choice(n_events, size=ln, replace=False)).tolist())
+    row_ptr, col = csr(rows)
+    base = oracle.quantify(row_ptr, col, p, cut_off=0.0, limit_order=0)
+    finite = base.row_logp[np.isfinite(base.row_logp)]
+    model = gpu_ctx.upload(row_ptr, col, n_events)
+    model.set_probabilities(p)
+    for q in (0.5, 0.9, 0.99, 0.999):
+        s_star = float(np.quantile(finite, q))
+        s_star = float(finite[np.argmin(np.abs(finite - s_star))])  # exactly some row's s_i
+        for cut in (math.exp(s_star), np.nextafter(math.exp(s_star), 0.0), np.nextafter(math.exp(s_star), 1.0)):
+            if not (0.0 < cut <= 1.0):
+                continue
+            want = oracle.quantify(row_ptr, col, p, cut_off=float(cut), limit_order=0)
+            for kern in (_capi.KERNEL_FILTER_REFINE, _capi.KERNEL_WAVE_STREAM, _capi.KERNEL_ROWS):
+                got = gpu_ctx.quantify(model, default_params(cut_off=float(cut), limit_order=0, flags=_capi.QUANT_KEEP_MASK,
+                                                             kernel=kern))
+                assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row), (q, cut, kern)
+                assert np.array_equal(gpu_ctx.fetch_keep_mask(model), want.keep_mask), (q, cut, kern)
+                assert rel(got.rare_event, want.rare_event) < TOL
+    model.close()
