@@ -197,7 +197,12 @@ __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const u
         if (tid < 64) sums[kFrSlabRows + tid] = 0.0; // the sink
         fr_barrier();
     }
-    if (lane == 0 && n_cand) atomicAdd(cand_count, n_cand); // lets the host see when the filter stops paying off
+    // The count lets the host see when the filter stops paying off. One global atomic per block (thousands
+    // of same-address atomics, one per wave, cost ~50 us); n_cand is wave-uniform, the sink is zero here.
+    unsigned long long* block_cand = reinterpret_cast<unsigned long long*>(sums + kFrSlabRows);
+    if (lane == 0 && n_cand) __hip_atomic_fetch_add(block_cand, n_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    fr_barrier();
+    if (tid == 0 && *block_cand) atomicAdd(cand_count, *block_cand);
 }
 
 // ---- pass A, quantised form ---------------------------------------------------------------------------
@@ -291,7 +296,12 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
         if (tid < 64) sums[kQ8SlabRows + tid] = 0u; // the sink
         fr_barrier();
     }
-    if (lane == 0 && n_cand) atomicAdd(cand_count, n_cand);
+    // one global atomic per block, as in k_fr_filter
+    // (n_cand is wave-uniform; the sink words are zero again here and 8-byte aligned)
+    unsigned long long* block_cand = reinterpret_cast<unsigned long long*>(sums + kQ8SlabRows);
+    if (lane == 0 && n_cand) __hip_atomic_fetch_add(block_cand, n_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    fr_barrier();
+    if (tid == 0 && *block_cand) atomicAdd(cand_count, *block_cand);
 }
 
 // ---- pass B ------------------------------------------------------------------------------------------
