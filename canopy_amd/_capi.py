@@ -27,6 +27,7 @@ UPLOAD_DEVICE_POINTERS = 2
 
 APPROX_RARE_EVENT, APPROX_MCUB, APPROX_BOTH = 1, 2, 3
 QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK = 1, 2, 4
+BATCH_LOG_INPUT = 1
 GATE_AND, GATE_OR, GATE_ATLEAST, GATE_XOR, GATE_NOT, GATE_NAND, GATE_NOR, GATE_NULL = range(8)
 KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER, KERNEL_FILTER_REFINE = range(6)
 
@@ -55,6 +56,11 @@ class Partial(C.Structure):
     _fields_ = [("rare_hi", C.c_double), ("rare_lo", C.c_double), ("log1p_hi", C.c_double),
                 ("log1p_lo", C.c_double), ("n_kept", C.c_double), ("n_certain", C.c_double),
                 ("max_logp", C.c_double), ("argmax_row", C.c_double)]
+
+
+class BatchInfo(C.Structure):
+    _fields_ = [("n_candidates", C.c_int64), ("nnz_candidates", C.c_int64), ("candidate_ms", C.c_double),
+                ("trials_ms", C.c_double), ("host_log_ms", C.c_double)]
 
 
 class DagView(C.Structure):
@@ -106,6 +112,11 @@ SIGNATURES = {
     "canopy_combine_partials": (C.c_int, [C.POINTER(Partial), C.c_int32, C.c_uint32, C.POINTER(QuantResult)]),
     "canopy_fetch_row_logp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "canopy_fetch_keep_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "canopy_quantify_batch_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(QuantParams), C.c_uint32,
+                                              C.c_void_p]),
+    "canopy_quantify_batch_fetch": (C.c_int, [C.c_void_p, C.POINTER(Partial), C.c_int32, C.POINTER(BatchInfo)]),
+    "canopy_quantify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(QuantParams), C.c_uint32,
+                                        C.POINTER(QuantResult), C.POINTER(BatchInfo)]),
     "canopy_dag_upload": (C.c_int, [C.c_void_p, C.POINTER(DagView), C.POINTER(C.c_void_p)]),
     "canopy_dag_free": (None, [C.c_void_p]),
     "canopy_dag_set_probabilities": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcanopy.so")
 
-SOURCES = ["canopy_api.hip", "kernels_rows.hip", "kernels_build.hip", "kernels_ws.hip", "kernels_vs.hip", "kernels_mc.hip", "kernels_fr.hip", "mef_lowering.cpp"]
+SOURCES = ["canopy_api.hip", "kernels_rows.hip", "kernels_build.hip", "kernels_ws.hip", "kernels_vs.hip", "kernels_mc.hip", "kernels_fr.hip",
+           "kernels_batch.hip", "mef_lowering.cpp"]
 HEADERS = ["canopy_device.h", "canopy_internal.h"]
 
 FLAGS = [
@@ -23,23 +24,44 @@ FLAGS = [
 ]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+OBJ_DIR = os.path.join(HERE, "build")
+
+
+def _deps_common():
+    return [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(ROOT, "include", "canopy.h"), os.path.abspath(__file__)]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "canopy.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+    """One object per source (compiled in parallel, only when stale), then one link."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    common = _deps_common()
+    flags = [f for f in FLAGS if f != "-shared"]
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, src + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [os.path.join(CSRC, src)] + common):
+            cmd = [hipcc] + flags + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, pr in jobs if pr.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    if force or jobs or _newer(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
     return LIB
 
 

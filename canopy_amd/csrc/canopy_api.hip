@@ -167,6 +167,7 @@ void canopy_ctx_free(canopy_ctx* ctx) {
     if (ctx->d_mc_hits) (void)hipFree(ctx->d_mc_hits);
     if (ctx->h_mc_hits) (void)hipHostFree(ctx->h_mc_hits);
     for (auto ev : ctx->ev_mc) if (ev) (void)hipEventDestroy(ev);
+    batch_state_free(ctx->batch);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

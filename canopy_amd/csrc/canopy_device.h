@@ -115,17 +115,45 @@ __device__ __forceinline__ void acc_load(Acc& a, const double* src) {
 // Contribution of one kept row to the two compensated sums: P = exp(s), log1p(-P).
 // For P < 2^-12 (every realistic rare-event cut set) log1p(-P) = -P(1 + P/2 + P^2/3 + P^3/4 + P^4/5 + P^5/6)
 // is exact to < 1e-19 relative; ocml's log1p runs only when some lane of the wave needs it.
-__device__ __forceinline__ void fold_kept_row(CSum& rare, CSum& l1p, double& n_certain, double s, bool on) {
-    const double P = on ? exp(s) : 0.0;
-    double l = -P * (1.0 + P * (0.5 + P * (1.0 / 3.0 + P * (0.25 + P * (0.2 + P * (1.0 / 6.0))))));
-    const bool big = on && P >= 0x1.0p-12;
-    if (__any(big)) {
-        if (big) l = (P < 1.0) ? log1p(-P) : 0.0;
-    }
+__device__ __forceinline__ double log1p_neg_small(double P) {
+    return -P * (1.0 + P * (0.5 + P * (1.0 / 3.0 + P * (0.25 + P * (0.2 + P * (1.0 / 6.0))))));
+}
+__device__ __forceinline__ void fold_terms(CSum& rare, CSum& l1p, double& n_certain, double P, double l, bool on) {
     if (on) {
         csum_add(rare, P);
         if (P < 1.0) csum_add(l1p, l); else n_certain += 1.0;
     }
+}
+__device__ __forceinline__ void fold_kept_row(CSum& rare, CSum& l1p, double& n_certain, double s, bool on) {
+    const double P = on ? exp(s) : 0.0;
+    double l = log1p_neg_small(P);
+    const bool big = on && P >= 0x1.0p-12;
+    if (__any(big)) {
+        if (big) l = (P < 1.0) ? log1p(-P) : 0.0;
+    }
+    fold_terms(rare, l1p, n_certain, P, l, on);
+}
+// N rows per lane at once: the N exp / polynomial chains are independent, so a lone wave on a SIMD overlaps
+// their latencies; the compensated adds then run in index order (same result as N fold_kept_row calls).
+template <int N>
+__device__ __forceinline__ void fold_kept_rows(CSum& rare, CSum& l1p, double& n_certain, const double (&s)[N],
+                                               const bool (&on)[N]) {
+    double P[N], l[N];
+    bool any_big = false;
+#pragma unroll
+    for (int u = 0; u < N; ++u) P[u] = on[u] ? exp(s[u]) : 0.0;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        l[u] = log1p_neg_small(P[u]);
+        any_big = any_big || (on[u] && P[u] >= 0x1.0p-12);
+    }
+    if (__any(any_big)) {
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+            if (on[u] && P[u] >= 0x1.0p-12) l[u] = (P[u] < 1.0) ? log1p(-P[u]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) fold_terms(rare, l1p, n_certain, P[u], l[u], on[u]);
 }
 
 // Per-row epilogue shared by every row kernel: filter, P = exp(s), both sums, argmax.

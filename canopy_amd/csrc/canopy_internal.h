@@ -9,6 +9,11 @@
 
 #include "canopy.h"
 
+namespace canopy {
+struct BatchState; // kernels_batch.hip
+void batch_state_free(BatchState* b);
+} // namespace canopy
+
 struct canopy_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -49,6 +54,8 @@ struct canopy_ctx {
     unsigned long long* h_mc_hits = nullptr; // pinned
     int64_t mc_last_trials = 0;
     hipEvent_t ev_mc[2] = {nullptr, nullptr};
+    // batched quantification (lazily created)
+    canopy::BatchState* batch = nullptr;
 
     std::string last_error;
 };

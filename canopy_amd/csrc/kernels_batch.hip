@@ -1,0 +1,490 @@
+// kernels_batch.hip -- batched quantification: K probability vectors ("trials") against ONE cut-set
+// model, gfx950 / wave64 only, plus its C ABI entry points.
+//
+// Reference side: only the vocabulary exists -- uncertainty analysis draws num_trials probability vectors
+// from the basic events' distributions (Settings::uncertainty_analysis / num_trials, reference
+// src/mef/openpsa/settings.h:118-130,281-295; deviates src/mef/openpsa/expr/random_deviate.h) and
+// quantifies the same cut sets under each. The caller supplies the K vectors; trial k's result is
+// defined as exactly what canopy_quantify returns for p = p_trials[k] (same canonical arithmetic).
+//
+// Running K full passes would stream the model K times (0.49 ms each at config 3). Instead:
+//   1. envelope  logp_max[j] = max_k logp[k][j]. IEEE addition is monotone in both operands, so the
+//      CSR-order fp64 chain satisfies s_i(trial k) <= s_i(envelope) for every k, bit for bit: a row that
+//      passes `s_i >= log(cut_off)` under ANY trial passes it under the envelope. No tolerance involved.
+//   2. ONE ordinary quantification pass under the envelope (any kernel variant; FILTER_REFINE at scale)
+//      with the keep mask requested = the union candidate set.
+//   3. the candidate rows are compacted into a small CSR (row ids, offsets, columns);
+//   4. k_batch_rows: lane per candidate row, T = 8 trials per lane. The log-probabilities are laid out
+//      [event][trial], so one entry costs one 64-byte contiguous read for 8 trials; each trial's sum is
+//      the same plain-add chain in CSR order as everywhere else, followed by the exact filter / exp /
+//      log1p / count / argmax of that trial.
+//   5. k_finalize_batch: deterministic reduce of the per-workgroup records, one workgroup per trial.
+// With the default cut-off ~1 % of the rows are candidates: K trials cost one pass + K cheap passes over
+// ~1 % of the model.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "canopy_device.h"
+#include "canopy_internal.h"
+
+using namespace canopy;
+
+namespace canopy {
+
+struct BatchState {
+    double* d_in = nullptr;        // [chunk][E] staging of host logs
+    int64_t in_cap = 0;
+    double* d_logpT = nullptr;     // [E][kpad]
+    int64_t logpT_cap = 0;
+    double* d_logp_max = nullptr;  // [E]
+    int64_t max_cap = 0;
+    int64_t* d_word_off = nullptr; // [n_words] inclusive scan of candidate counts per mask word
+    int64_t word_cap = 0;
+    int64_t* d_c_row = nullptr;    // [n_c] local row index of candidate i (ascending)
+    int64_t c_row_cap = 0;
+    int64_t* d_c_row_ptr = nullptr;// [n_c + 1]
+    int64_t c_cap = 0;
+    int32_t* d_c_col = nullptr;    // [nnz_c]
+    int64_t col_cap = 0;
+    double* d_parts = nullptr;     // [blocks][kpad][8]
+    int64_t parts_cap = 0;
+    double* d_out = nullptr;       // [kpad][8] canopy_partial records
+    int64_t out_cap = 0;
+    double* h_out = nullptr;       // pinned mirror
+    int64_t h_out_cap = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // last batch
+    int32_t n_trials = 0;
+    double* last_out = nullptr;    // where the records of the last batch live (d_out or the caller's buffer)
+    int64_t n_candidates = 0, nnz_candidates = 0;
+    double host_log_ms = 0.0;
+};
+
+void batch_state_free(BatchState* b) {
+    if (!b) return;
+    void* ptrs[] = {b->d_in, b->d_logpT, b->d_logp_max, b->d_word_off, b->d_c_row, b->d_c_row_ptr, b->d_c_col, b->d_parts, b->d_out};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (b->h_out) (void)hipHostFree(b->h_out);
+    for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+} // namespace canopy
+
+namespace {
+
+constexpr int kBatchT = 8;       // trials per lane
+constexpr int kBatchThreads = 256;
+constexpr int kBatchWaves = kBatchThreads / kWave;
+constexpr int kInChunk = 64;     // trials staged per host->device copy
+
+int grid_for(int64_t n, int block, int64_t cap = (1 << 20)) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+canopy_status fail(canopy_ctx* ctx, canopy_status st, const std::string& msg) {
+    if (ctx) ctx->last_error = msg;
+    return st;
+}
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            (void)hipGetLastError();                                                                    \
+            return fail((ctx), _e == hipErrorOutOfMemory ? CANOPY_ERR_OUT_OF_MEMORY : CANOPY_ERR_HIP,   \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                             \
+        }                                                                                               \
+    } while (0)
+
+template <typename T>
+hipError_t grow(T** p, int64_t* cap, int64_t need) {
+    if (need <= *cap && *p) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc(p, sizeof(T) * (size_t)(need > 0 ? need : 1));
+    if (e == hipSuccess) *cap = need > 0 ? need : 1;
+    return e;
+}
+
+// ---- layout kernels ---------------------------------------------------------------------------------
+
+// in [n_k][E] (trial-major staging chunk)  ->  out[e * kpad + k0 + k]; 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void k_batch_transpose(const double* __restrict__ in, int32_t n_k, int32_t n_events,
+                                                         double* __restrict__ out, int32_t kpad, int32_t k0) {
+    __shared__ double tile[64][65];
+    const int e0 = blockIdx.x * 64, kk0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 64 x 4
+    for (int r = ty; r < 64; r += 4) {
+        const int k = kk0 + r, e = e0 + tx;
+        tile[r][tx] = (k < n_k && e < n_events) ? in[(size_t)k * n_events + e] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int e = e0 + r, k = kk0 + tx;
+        if (e < n_events && k < n_k) out[(size_t)e * kpad + k0 + k] = tile[tx][r];
+    }
+}
+
+// envelope: logp_max[e] = max over the trials; also clears the padding columns [n_trials, kpad)
+__global__ __launch_bounds__(256) void k_batch_colmax(double* __restrict__ logpT, int32_t n_events, int32_t kpad,
+                                                      int32_t n_trials, double* __restrict__ logp_max) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_events) return;
+    double* row = logpT + (size_t)e * kpad;
+    double m = -__builtin_inf();
+    for (int k = 0; k < n_trials; ++k) m = row[k] > m ? row[k] : m;
+    for (int k = n_trials; k < kpad; ++k) row[k] = 0.0;
+    logp_max[e] = m;
+}
+
+__global__ __launch_bounds__(256) void k_batch_popc(const uint64_t* __restrict__ mask, int64_t n_words, int64_t n_rows,
+                                                    int64_t* __restrict__ cnt) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint64_t m = mask[w];
+    const int64_t left = n_rows - w * 64;
+    if (left < 64) m &= (1ULL << left) - 1ULL;
+    cnt[w] = (int64_t)__builtin_popcountll(m);
+}
+
+// candidate i (ascending row order) -> its local row index and its length (into c_row_ptr[i + 1])
+__global__ __launch_bounds__(256) void k_batch_compact_rows(const uint64_t* __restrict__ mask, int64_t n_words, int64_t n_rows,
+                                                            const int64_t* __restrict__ word_incl,
+                                                            const int64_t* __restrict__ row_ptr, int64_t* __restrict__ c_row,
+                                                            int64_t* __restrict__ c_row_ptr) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w == 0) c_row_ptr[0] = 0;
+    if (w >= n_words) return;
+    uint64_t m = mask[w];
+    const int64_t left = n_rows - w * 64;
+    if (left < 64) m &= (1ULL << left) - 1ULL;
+    int64_t i = word_incl[w] - (int64_t)__builtin_popcountll(m);
+    for (; m != 0ULL; m &= m - 1) {
+        const int64_t r = w * 64 + __builtin_ctzll(m);
+        c_row[i] = r;
+        c_row_ptr[i + 1] = row_ptr[r + 1] - row_ptr[r];
+        ++i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_batch_compact_cols(const int64_t* __restrict__ c_row, const int64_t* __restrict__ c_row_ptr,
+                                                            int64_t n_c, const int64_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ col_idx, int32_t* __restrict__ c_col) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_c) return;
+    const int64_t src = row_ptr[c_row[i]], dst = c_row_ptr[i], len = c_row_ptr[i + 1] - dst;
+    for (int64_t k = 0; k < len; ++k) c_col[dst + k] = col_idx[src + k];
+}
+
+// ---- the K-trial row kernel ---------------------------------------------------------------------------
+struct BatchArgs {
+    const int64_t* c_row;
+    const int64_t* c_row_ptr;
+    const int32_t* c_col;
+    const double* logpT; // [E][kpad]
+    int64_t n_c;
+    int64_t row_offset;
+    int32_t kpad;
+    int32_t limit_order;
+    double log_cut;
+    double* parts; // [gridDim.x][kpad][8]
+};
+
+__global__ __launch_bounds__(kBatchThreads) void k_batch_rows(BatchArgs a) {
+    __shared__ double s_red[kBatchWaves][kBatchT][kAccDoubles];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const int k0 = blockIdx.y * kBatchT;
+    Acc acc[kBatchT];
+#pragma unroll
+    for (int t = 0; t < kBatchT; ++t) acc_init(acc[t]);
+    const int64_t stride = (int64_t)gridDim.x * kBatchThreads;
+    const int64_t n_pad = (a.n_c + kWave - 1) / kWave * kWave; // whole waves stay together (ballots inside)
+    for (int64_t i = (int64_t)blockIdx.x * kBatchThreads + tid; i < n_pad; i += stride) {
+        const bool valid = i < a.n_c;
+        const int64_t b = valid ? a.c_row_ptr[i] : 0, e = valid ? a.c_row_ptr[i + 1] : 0;
+        double s[kBatchT];
+#pragma unroll
+        for (int t = 0; t < kBatchT; ++t) s[t] = 0.0;
+        for (int64_t k = b; k < e; k += 2) { // two entries per step: 16 independent 8-byte values in flight
+            const bool two = k + 1 < e;
+            const int32_t c0 = a.c_col[k];
+            const int32_t c1 = two ? a.c_col[k + 1] : c0;
+            const double4* p0 = reinterpret_cast<const double4*>(a.logpT + (size_t)c0 * a.kpad + k0);
+            const double4* p1 = reinterpret_cast<const double4*>(a.logpT + (size_t)c1 * a.kpad + k0);
+            const double4 v00 = p0[0], v01 = p0[1], v10 = p1[0], v11 = p1[1];
+            const double x0[kBatchT] = {v00.x, v00.y, v00.z, v00.w, v01.x, v01.y, v01.z, v01.w};
+            const double x1[kBatchT] = {v10.x, v10.y, v10.z, v10.w, v11.x, v11.y, v11.z, v11.w};
+#pragma unroll
+            for (int t = 0; t < kBatchT; ++t) s[t] = s[t] + x0[t]; // plain adds, CSR order
+            if (two) {
+#pragma unroll
+                for (int t = 0; t < kBatchT; ++t) s[t] = s[t] + x1[t];
+            }
+        }
+        const int len = (int)(e - b);
+        const double grow = valid ? (double)(a.row_offset + a.c_row[i]) : -1.0;
+#pragma unroll
+        for (int t = 0; t < kBatchT; ++t) row_epilogue(acc[t], s[t], len, valid, a.log_cut, a.limit_order, grow);
+    }
+#pragma unroll
+    for (int t = 0; t < kBatchT; ++t) {
+        acc_wave_reduce(acc[t]);
+        if (lane == 0) acc_store(&s_red[wave][t][0], acc[t]);
+    }
+    __syncthreads();
+    if (tid < kBatchT) {
+        Acc r;
+        acc_load(r, &s_red[0][tid][0]);
+        for (int w = 1; w < kBatchWaves; ++w) {
+            Acc o;
+            acc_load(o, &s_red[w][tid][0]);
+            acc_merge(r, o);
+        }
+        acc_store(a.parts + ((size_t)blockIdx.x * a.kpad + k0 + tid) * kAccDoubles, r);
+    }
+}
+
+// one workgroup per trial: fixed thread <- record assignment, fixed tree (as k_finalize)
+__global__ __launch_bounds__(256) void k_finalize_batch(const double* __restrict__ parts, int n_blocks, int32_t kpad,
+                                                        double* __restrict__ out) {
+    __shared__ double s_red[4 * kAccDoubles];
+    const int k = blockIdx.x;
+    Acc acc;
+    acc_init(acc);
+    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+        Acc o;
+        acc_load(o, parts + ((size_t)i * kpad + k) * kAccDoubles);
+        acc_merge(acc, o);
+    }
+    acc_wave_reduce(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) acc_store(s_red + wave * kAccDoubles, acc);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Acc t;
+        acc_load(t, s_red);
+        for (int w = 1; w < 4; ++w) {
+            Acc o;
+            acc_load(o, s_red + w * kAccDoubles);
+            acc_merge(t, o);
+        }
+        const double rh = t.rare.s + t.rare.c;
+        const double rl = (t.rare.s - rh) + t.rare.c;
+        const double lh = t.l1p.s + t.l1p.c;
+        const double ll = (t.l1p.s - lh) + t.l1p.c;
+        double* o = out + (size_t)k * kAccDoubles;
+        o[0] = rh; o[1] = rl; o[2] = lh; o[3] = ll;
+        o[4] = t.n_kept; o[5] = t.n_certain; o[6] = t.max_logp; o[7] = t.argmax;
+    }
+}
+
+void log_rows(const double* p, double* out, int64_t n, bool is_log, int* bad) {
+    for (int64_t i = 0; i < n; ++i) {
+        const double v = p[i];
+        if (is_log) {
+            if (!(v <= 0.0)) *bad = 1; // NaN or a log-probability above 0
+            out[i] = v;
+        } else {
+            if (!(v >= 0.0 && v <= 1.0)) *bad = 1;
+            out[i] = log(v); // glibc log on the host: the canonical logp of canopy_model_set_probabilities
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* m, const double* p_trials, int32_t n_trials,
+                                          const canopy_quant_params* params, uint32_t batch_flags, void* device_out) {
+    if (!ctx || !m || !p_trials || n_trials < 1) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (m->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "model lives on another device");
+    canopy_quant_params prm;
+    if (params) prm = *params; else canopy_quant_params_default(&prm);
+    if (prm.limit_order < 0 || !(prm.cut_off >= 0.0)) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "limit_order < 0 or cut_off < 0");
+    if (prm.flags & CANOPY_QUANT_ROW_LOGP)
+        return fail(ctx, CANOPY_ERR_UNSUPPORTED, "per-row output is not available for a batch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->batch) {
+        ctx->batch = new (std::nothrow) BatchState();
+        if (!ctx->batch) return CANOPY_ERR_OUT_OF_MEMORY;
+        for (auto& e : ctx->batch->ev) HIP_TRY(ctx, hipEventCreate(&e));
+    }
+    BatchState* b = ctx->batch;
+    const int32_t E = m->n_events;
+    const int32_t kpad = (n_trials + kBatchT - 1) / kBatchT * kBatchT;
+    const bool is_log = (batch_flags & CANOPY_BATCH_LOG_INPUT) != 0;
+
+    // ---- 1. host logs (threaded), staged in chunks of trials, transposed on the device to [E][kpad]
+    HIP_TRY(ctx, grow(&b->d_logpT, &b->logpT_cap, (int64_t)E * kpad));
+    HIP_TRY(ctx, grow(&b->d_logp_max, &b->max_cap, (int64_t)E));
+    HIP_TRY(ctx, grow(&b->d_in, &b->in_cap, (int64_t)std::min<int32_t>(kInChunk, n_trials) * E));
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<double> h((size_t)std::min<int32_t>(kInChunk, n_trials) * (size_t)E);
+        unsigned hw = std::thread::hardware_concurrency();
+        const int n_thr = (int)std::max(1u, std::min(hw ? hw : 1u, 32u));
+        for (int32_t c0 = 0; c0 < n_trials; c0 += kInChunk) {
+            const int32_t nk = std::min<int32_t>(kInChunk, n_trials - c0);
+            const int64_t total = (int64_t)nk * E;
+            std::vector<int> bad((size_t)n_thr, 0);
+            if (total < (1 << 16) || n_thr == 1) {
+                log_rows(p_trials + (size_t)c0 * E, h.data(), total, is_log, &bad[0]);
+            } else {
+                std::vector<std::thread> thr;
+                for (int t = 0; t < n_thr; ++t) {
+                    const int64_t lo = total * t / n_thr, hi = total * (t + 1) / n_thr;
+                    thr.emplace_back(log_rows, p_trials + (size_t)c0 * E + lo, h.data() + lo, hi - lo, is_log, &bad[(size_t)t]);
+                }
+                for (auto& th : thr) th.join();
+            }
+            for (int v : bad)
+                if (v) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, is_log ? "a log-probability is NaN or above 0" : "a probability is outside [0,1]");
+            if (total > 0) {
+                HIP_TRY(ctx, hipMemcpyAsync(b->d_in, h.data(), sizeof(double) * (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_batch_transpose, dim3((E + 63) / 64, (nk + 63) / 64), dim3(256), 0, ctx->stream,
+                                   (const double*)b->d_in, nk, E, b->d_logpT, kpad, c0);
+                HIP_TRY(ctx, hipGetLastError());
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // h is reused by the next chunk
+            }
+        }
+        b->host_log_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (E > 0) {
+        hipLaunchKernelGGL(k_batch_colmax, dim3(grid_for(E, 256)), dim3(256), 0, ctx->stream, b->d_logpT, E, kpad, n_trials, b->d_logp_max);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+
+    // ---- 2. candidate pass: an ordinary quantification under the envelope, keep mask requested
+    HIP_TRY(ctx, hipEventRecord(b->ev[0], ctx->stream));
+    canopy_quant_params cprm = prm;
+    cprm.flags = (prm.flags | CANOPY_QUANT_KEEP_MASK) & ~(uint32_t)CANOPY_QUANT_ROW_LOGP;
+    double* const saved_logp = m->d_logp;
+    const bool saved_has_p = m->has_p;
+    const bool was_timing = ctx->timing_on;
+    m->d_logp = b->d_logp_max;
+    m->has_p = true;
+    ctx->timing_on = false;
+    canopy_status st = canopy_quantify_async(ctx, m, &cprm);
+    canopy_partial env;
+    if (st == CANOPY_OK) st = canopy_quantify_fetch(ctx, &env);
+    m->d_logp = saved_logp;
+    m->has_p = saved_has_p;
+    ctx->timing_on = was_timing;
+    if (st != CANOPY_OK) return st;
+    const int64_t n_c = (int64_t)env.n_kept;
+    const int64_t n_words = (m->n_rows + 63) / 64;
+
+    // ---- 3. compact the candidates
+    int64_t nnz_c = 0;
+    HIP_TRY(ctx, grow(&b->d_c_row_ptr, &b->c_cap, n_c + 1));
+    HIP_TRY(ctx, grow(&b->d_c_row, &b->c_row_cap, n_c));
+    if (n_c > 0) {
+        HIP_TRY(ctx, grow(&b->d_word_off, &b->word_cap, n_words));
+        hipLaunchKernelGGL(k_batch_popc, dim3(grid_for(n_words, 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t*)ctx->d_keep_mask, n_words, m->n_rows, b->d_word_off);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, scan_inclusive_i64(b->d_word_off, n_words, ctx->stream));
+        hipLaunchKernelGGL(k_batch_compact_rows, dim3(grid_for(n_words, 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t*)ctx->d_keep_mask, n_words, m->n_rows, (const int64_t*)b->d_word_off,
+                           (const int64_t*)m->d_row_ptr, b->d_c_row, b->d_c_row_ptr);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, scan_inclusive_i64(b->d_c_row_ptr + 1, n_c, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&nnz_c, b->d_c_row_ptr + n_c, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, grow(&b->d_c_col, &b->col_cap, nnz_c));
+        hipLaunchKernelGGL(k_batch_compact_cols, dim3(grid_for(n_c, 256)), dim3(256), 0, ctx->stream,
+                           (const int64_t*)b->d_c_row, (const int64_t*)b->d_c_row_ptr, n_c, (const int64_t*)m->d_row_ptr,
+                           (const int32_t*)m->d_col_idx, b->d_c_col);
+        HIP_TRY(ctx, hipGetLastError());
+    } else {
+        HIP_TRY(ctx, grow(&b->d_c_col, &b->col_cap, 1));
+    }
+    HIP_TRY(ctx, hipEventRecord(b->ev[1], ctx->stream));
+
+    // ---- 4. K trials over the compact CSR, 5. one record per trial
+    const int n_chunks = kpad / kBatchT;
+    int64_t gx = (8 * (int64_t)ctx->n_cu + n_chunks - 1) / n_chunks; // ~8 workgroups per CU in total
+    const int64_t gx_max = (n_c + kBatchThreads - 1) / kBatchThreads;
+    if (gx > gx_max) gx = gx_max;
+    if (gx < 1) gx = 1;
+    HIP_TRY(ctx, grow(&b->d_parts, &b->parts_cap, gx * kpad * kAccDoubles));
+    HIP_TRY(ctx, grow(&b->d_out, &b->out_cap, (int64_t)kpad * kAccDoubles));
+    BatchArgs a;
+    a.c_row = b->d_c_row; a.c_row_ptr = b->d_c_row_ptr; a.c_col = b->d_c_col; a.logpT = b->d_logpT;
+    a.n_c = n_c; a.row_offset = m->row_offset; a.kpad = kpad; a.limit_order = prm.limit_order;
+    a.log_cut = prm.cut_off > 0.0 ? log(prm.cut_off) : -INFINITY;
+    a.parts = b->d_parts;
+    hipLaunchKernelGGL(k_batch_rows, dim3((unsigned)gx, (unsigned)n_chunks), dim3(kBatchThreads), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    double* out = device_out ? static_cast<double*>(device_out) : b->d_out;
+    hipLaunchKernelGGL(k_finalize_batch, dim3((unsigned)n_trials), dim3(256), 0, ctx->stream, (const double*)b->d_parts, (int)gx, kpad, out);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(b->ev[2], ctx->stream));
+    b->n_trials = n_trials;
+    b->last_out = out;
+    b->n_candidates = n_c;
+    b->nnz_candidates = nnz_c;
+    return CANOPY_OK;
+}
+
+canopy_status canopy_quantify_batch_fetch(canopy_ctx* ctx, canopy_partial* partials, int32_t n_trials, canopy_batch_info* info) {
+    if (!ctx || !partials) return CANOPY_ERR_INVALID_ARGUMENT;
+    BatchState* b = ctx->batch;
+    if (!b || b->n_trials == 0) return fail(ctx, CANOPY_ERR_STATE, "no batch has been enqueued");
+    if (n_trials != b->n_trials) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "n_trials differs from the enqueued batch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n = (int64_t)n_trials * kAccDoubles;
+    if (b->h_out_cap < n) {
+        if (b->h_out) (void)hipHostFree(b->h_out);
+        b->h_out = nullptr; b->h_out_cap = 0;
+        HIP_TRY(ctx, hipHostMalloc(&b->h_out, sizeof(double) * (size_t)n));
+        b->h_out_cap = n;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(b->h_out, b->last_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(partials, b->h_out, sizeof(double) * (size_t)n);
+    if (info) {
+        float c = 0.f, t = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&c, b->ev[0], b->ev[1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&t, b->ev[1], b->ev[2]));
+        info->n_candidates = b->n_candidates;
+        info->nnz_candidates = b->nnz_candidates;
+        info->candidate_ms = c;
+        info->trials_ms = t;
+        info->host_log_ms = b->host_log_ms;
+    }
+    return CANOPY_OK;
+}
+
+canopy_status canopy_quantify_batch(canopy_ctx* ctx, canopy_model* m, const double* p_trials, int32_t n_trials,
+                                    const canopy_quant_params* params, uint32_t batch_flags, canopy_quant_result* results,
+                                    canopy_batch_info* info) {
+    if (!results) return CANOPY_ERR_INVALID_ARGUMENT;
+    canopy_status st = canopy_quantify_batch_async(ctx, m, p_trials, n_trials, params, batch_flags, nullptr);
+    if (st != CANOPY_OK) return st;
+    std::vector<canopy_partial> parts((size_t)n_trials);
+    canopy_batch_info bi;
+    st = canopy_quantify_batch_fetch(ctx, parts.data(), n_trials, &bi);
+    if (st != CANOPY_OK) return st;
+    for (int32_t k = 0; k < n_trials; ++k) {
+        st = canopy_combine_partials(&parts[(size_t)k], 1, params ? params->flags : 0, &results[k]);
+        if (st != CANOPY_OK) return st;
+        results[k].elapsed_kernel_ms = (bi.candidate_ms + bi.trials_ms) / n_trials;
+    }
+    if (info) *info = bi;
+    return CANOPY_OK;
+}
+
+} // extern "C"

@@ -154,7 +154,21 @@ __device__ __noinline__ void ws_epilogue(double* sums, int64_t t, int lane, Acc*
             if (keep_mask_out != nullptr && lane == 0 && r < n_rows) keep_mask_out[r >> 6] = m;
         }
     }
-    for (int j = 0; j < n_comp; j += kWave) {
+    int j = 0;
+    for (; j + kWave < n_comp; j += 4 * kWave) { // more than one 64-row batch left: four independent exp chains
+        double sv[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            on[u] = j + u * kWave + lane < n_comp;
+            sv[u] = on[u] ? sums[comp_base + j + u * kWave + lane] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (on[u]) sums[comp_base + j + u * kWave + lane] = 0.0;
+        fold_kept_rows<4>(acc.rare, acc.l1p, acc.n_certain, sv, on);
+    }
+    for (; j < n_comp; j += kWave) {
         const bool on = j + lane < n_comp;
         const double sv = on ? sums[comp_base + j + lane] : 0.0;
         if (on) sums[comp_base + j + lane] = 0.0;

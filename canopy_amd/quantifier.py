@@ -101,6 +101,32 @@ class Context:
         return QuantResult(res.rare_event, res.mcub, res.n_kept, res.argmax_row, res.max_logp,
                            res.elapsed_kernel_ms)
 
+    # -- batched quantification: K probability vectors against one model (N4) ----------------------
+    def quantify_batch_async(self, model, p_trials, params=None, log_input=False, device_out=None):
+        """p_trials: [n_trials, n_events]. device_out: raw device pointer (int) for the records, or None."""
+        p_trials = _as(p_trials, np.float64)
+        if p_trials.ndim != 2 or p_trials.shape[1] != model.info().n_events:
+            raise ValueError("p_trials must be [n_trials, n_events]")
+        capi.check(capi.lib().canopy_quantify_batch_async(self._h, model.handle, p_trials.ctypes.data, p_trials.shape[0],
+                                                          C.byref(params) if params else None,
+                                                          capi.BATCH_LOG_INPUT if log_input else 0, device_out),
+                   "canopy_quantify_batch_async", self._h)
+        return p_trials.shape[0]
+
+    def fetch_batch_partials(self, n_trials):
+        parts = (capi.Partial * n_trials)()
+        info = capi.BatchInfo()
+        capi.check(capi.lib().canopy_quantify_batch_fetch(self._h, parts, n_trials, C.byref(info)),
+                   "canopy_quantify_batch_fetch", self._h)
+        return list(parts), info
+
+    def quantify_batch(self, model, p_trials, params=None, log_input=False):
+        """-> (list of QuantResult, BatchInfo); trial k == quantify() after set_probabilities(p_trials[k])."""
+        n = self.quantify_batch_async(model, p_trials, params, log_input)
+        parts, info = self.fetch_batch_partials(n)
+        flags = params.flags if params else 0
+        return [combine_partials([q], flags) for q in parts], info
+
     def last_kernel_ms(self):
         a, b = C.c_double(), C.c_double()
         capi.check(capi.lib().canopy_last_kernel_ms(self._h, C.byref(a), C.byref(b)), "canopy_last_kernel_ms", self._h)

@@ -268,6 +268,46 @@ CANOPY_API canopy_status canopy_fetch_keep_mask(canopy_ctx* ctx, const canopy_mo
 CANOPY_API canopy_status canopy_last_kernel_ms(canopy_ctx* ctx, double* row_kernel_ms,
                                                double* total_ms);
 
+/* ---- N4: batched quantification -- K probability vectors ("trials") against one model ------------- */
+/*
+ * Reference vocabulary: uncertainty analysis quantifies the same cut sets under num_trials sampled
+ * probability vectors (Settings::uncertainty_analysis / num_trials, src/mef/openpsa/settings.h:118-130,
+ * 281-295; the deviates of src/mef/openpsa/expr/random_deviate.h draw them). The reference has no
+ * implementation. Semantics here: p_trials is a host array [n_trials][n_events], row-major; the record of
+ * trial k is exactly what canopy_quantify_async + canopy_quantify_fetch deliver after
+ * canopy_model_set_probabilities(p_trials[k]) -- integer outputs bit-exact, sums to <= 1e-12 relative.
+ * How: one ordinary pass under the element-wise maximum of the trials finds every row that can survive
+ * the cut-off in ANY trial (IEEE addition is monotone, so this needs no tolerance); those rows are
+ * compacted and each trial is evaluated exactly on the compact CSR, 8 trials per lane. The model's own
+ * probabilities (canopy_model_set_probabilities) are neither needed nor changed.
+ */
+enum {
+    CANOPY_BATCH_LOG_INPUT = 1u /* p_trials already holds natural logarithms (<= 0); skips the host log */
+};
+
+typedef struct canopy_batch_info {
+    int64_t n_candidates;   /* rows that survive under the envelope of the trials */
+    int64_t nnz_candidates;
+    double candidate_ms;    /* device time: envelope pass + compaction */
+    double trials_ms;       /* device time: all trials over the compact CSR + their final reduce */
+    double host_log_ms;     /* host time: log(p) of n_trials * n_events values, staging, transpose */
+} canopy_batch_info;
+
+/* Enqueue the batch. device_out: NULL, or a device buffer of n_trials * CANOPY_PARTIAL_DOUBLES doubles that
+   receives the records (e.g. this rank's slot of an all-gather buffer). Blocks on the host while it
+   sizes the compact CSR; the trial kernels are left running on the context's stream. */
+CANOPY_API canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* model, const double* p_trials,
+                                                     int32_t n_trials, const canopy_quant_params* params,
+                                                     uint32_t batch_flags, void* device_out);
+/* Wait, copy the n_trials records of this shard to the host. info may be NULL. */
+CANOPY_API canopy_status canopy_quantify_batch_fetch(canopy_ctx* ctx, canopy_partial* partials, int32_t n_trials,
+                                                     canopy_batch_info* info);
+/* Synchronous, single shard: results[n_trials]. info may be NULL. */
+CANOPY_API canopy_status canopy_quantify_batch(canopy_ctx* ctx, canopy_model* model, const double* p_trials,
+                                               int32_t n_trials, const canopy_quant_params* params,
+                                               uint32_t batch_flags, canopy_quant_result* results,
+                                               canopy_batch_info* info);
+
 /* ---- K6: direct Monte-Carlo propagation through the gate DAG ------------------------------------ */
 /*
  * Reference vocabulary: Approximation::kMonteCarlo (src/mef/openpsa/settings.h:19), num_trials and
