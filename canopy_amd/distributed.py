@@ -63,3 +63,45 @@ class ShardCombiner:
 
     def result(self, flags=0):
         return combine_partials(self.partials(), flags)
+
+
+class BatchCombiner:
+    """K5 for a batch (N4): every rank holds n_trials shard records; ONE all-gather of
+    n_trials * 64 B per rank delivers all of them to all ranks, and each trial is folded over the
+    ranks in rank order (canopy_combine_partials) -> identical results everywhere. On the GPU the
+    trial kernels write straight into `local` (pass `device_out_ptr()` to quantify_batch_async)."""
+
+    def __init__(self, n_trials, ctx=None, group=None, device=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.ctx = ctx
+        self.n_trials = n_trials
+        if device is None:
+            device = torch.device("cuda", ctx.device) if ctx is not None else torch.device("cpu")
+        n = n_trials * capi.PARTIAL_DOUBLES
+        self.local = torch.zeros(n, dtype=torch.float64, device=device)
+        self.gathered = torch.zeros(self.world * n, dtype=torch.float64, device=device)
+
+    def device_out_ptr(self):
+        return self.local.data_ptr()
+
+    def put_local(self, partials):
+        """CPU / test path: this rank's n_trials records (sequence of capi.Partial)."""
+        rec = np.concatenate([np.frombuffer(bytes(q), dtype=np.float64) for q in partials])
+        self.local.copy_(torch.from_numpy(rec.copy()).to(self.local.device))
+
+    def all_gather(self):
+        """The single collective of the batch (same stream discipline as ShardCombiner.all_reduce)."""
+        if self.world > 1:
+            n = self.local.numel()
+            dist.all_gather([self.gathered[r * n:(r + 1) * n] for r in range(self.world)], self.local, group=self.group)
+        else:
+            self.gathered.copy_(self.local)
+
+    def results(self, flags=0):
+        if self.ctx is not None:
+            self.ctx.synchronize()
+        host = self.gathered.detach().to("cpu").numpy().reshape(self.world, self.n_trials, capi.PARTIAL_DOUBLES)
+        return [combine_partials([capi.Partial(*host[r, k].tolist()) for r in range(self.world)], flags)
+                for k in range(self.n_trials)]

@@ -131,3 +131,25 @@ def test_batch_argument_errors(gpu_ctx):
     after = gpu_ctx.quantify(model)
     assert (before.rare_event, before.n_kept, before.argmax_row) == (after.rare_event, after.n_kept, after.argmax_row)
     model.close()
+
+
+def test_batch_records_into_a_caller_device_buffer(gpu_ctx):
+    """The multi-GPU route: the trial kernels write this rank's records into the all-gather slot."""
+    import canopy_amd
+    from canopy_amd.distributed import BatchCombiner
+    n_events, n_trials = 800, 11
+    p = canopy_amd.synthetic_probabilities(SEED, n_events)
+    pt = trials_from(p, n_trials, 0.4, 2)
+    model = gpu_ctx.synthetic(SEED, 60_000, n_events, 5, first_row=7_000_000)
+    prm = canopy_amd.default_params()
+    want, _ = gpu_ctx.quantify_batch(model, pt, prm)
+    comb = BatchCombiner(n_trials, ctx=gpu_ctx)
+    gpu_ctx.quantify_batch_async(model, pt, prm, device_out=comb.device_out_ptr())
+    gpu_ctx.synchronize()
+    comb.all_gather()
+    got = comb.results()
+    for g, w in zip(got, want):
+        assert (g.rare_event, g.mcub, g.n_kept, g.argmax_row, g.max_logp) == (w.rare_event, w.mcub, w.n_kept, w.argmax_row,
+                                                                              w.max_logp)
+        assert w.argmax_row >= 7_000_000
+    model.close()

@@ -64,3 +64,55 @@ def test_sharded_quantification_gloo(tmp_path, oracle, canopy_lib, world):
     assert n_kept == whole.n_kept and argmax == whole.argmax_row and max_logp == whole.max_logp
     assert abs(rare - whole.rare_event) <= 1e-12 * whole.rare_event
     assert abs(mcub - whole.mcub) <= 1e-12 * whole.mcub
+
+
+def _batch_worker(rank, world, port, n_rows, n_trials, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import oracle_py
+    from canopy_amd import _capi, shard_rows
+    from canopy_amd.distributed import BatchCombiner
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        row_ptr, col = oracle_py.synth_csr(SEED, n_rows, 1000, 6)
+        pt = _trials(oracle_py.synth_probabilities(SEED, 1000), n_trials)
+        b = shard_rows(row_ptr, world)
+        rp = row_ptr[b[rank]:b[rank + 1] + 1]
+        parts = []
+        for k in range(n_trials):
+            q = oracle_py.quantify(rp - rp[0], col[rp[0]:rp[-1]], pt[k], cut_off=1e-10, row_offset=int(b[rank]),
+                                   want_rows=False).res
+            parts.append(_capi.Partial(q.rare_hi, q.rare_lo, q.log1p_hi, q.log1p_lo, q.n_kept, q.n_certain, q.max_logp,
+                                       q.argmax_row))
+        comb = BatchCombiner(n_trials)
+        comb.put_local(parts)
+        comb.all_gather()  # the one collective of the batch
+        res = comb.results()
+        np.save(os.path.join(out_dir, "b%d.npy" % rank),
+                np.array([[r.rare_event, r.mcub, r.n_kept, r.argmax_row, r.max_logp] for r in res]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _trials(p, n_trials):
+    rng = np.random.default_rng(3)
+    return np.minimum(1.0, p[None, :] * np.exp(0.5 * rng.standard_normal((n_trials, p.size))))
+
+
+def test_sharded_batch_gloo(tmp_path, oracle, canopy_lib):
+    world, n_rows, n_trials = 2, 20000, 5
+    mp.spawn(_batch_worker, args=(world, _free_port(), n_rows, n_trials, str(tmp_path)), nprocs=world, join=True)
+    row_ptr, col = oracle.synth_csr(SEED, n_rows, 1000, 6)
+    pt = _trials(oracle.synth_probabilities(SEED, 1000), n_trials)
+    res = [np.load(os.path.join(str(tmp_path), "b%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(res[0], res[1])
+    for k in range(n_trials):
+        whole = oracle.quantify(row_ptr, col, pt[k], cut_off=1e-10, want_rows=False)
+        rare, mcub, n_kept, argmax, max_logp = res[0][k]
+        assert n_kept == whole.n_kept and argmax == whole.argmax_row and max_logp == whole.max_logp
+        assert abs(rare - whole.rare_event) <= 1e-12 * whole.rare_event
+        assert abs(mcub - whole.mcub) <= 1e-12 * whole.mcub
