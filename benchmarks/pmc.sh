@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes over bench.py (one counter group per run; no tracing flags -- gpurun refuses the mix).
 # usage: benchmarks/pmc.sh <outdir> [bench args...]     (each pass is bounded by `timeout`)
+# PMC_SCRIPT=benchmarks/bench_mc.py PMC_ARGS="--steps 1" profiles another driver (default: bench.py, 3 steps)
 set -u
 OUT=$1; shift
 mkdir -p "$OUT"
@@ -14,7 +15,7 @@ for grp in \
   "WRITE_SIZE TCC_HIT TCC_MISS" ; do
   i=$((i+1))
   echo "pass $i: $grp" >> "$OUT/progress.log"
-  timeout -k 10 150 rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -o pmc -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed rc=$?" >> "$OUT/progress.log"
+  timeout -k 10 150 rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -o pmc -- python3 "$GRAFT_REPO_ROOT/${PMC_SCRIPT:-bench.py}" ${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline} "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed rc=$?" >> "$OUT/progress.log"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections, re
@@ -23,8 +24,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        m = re.search(r"(k_fr_filter_q8|k_fr_filter|k_fr_refine|k_ws_build|k_fr_build|k_ws|k_rows|k_vs|k_finalize)", k)
-        if m and m.group(1) in ("k_ws", "k_rows", "k_vs", "k_fr_filter_q8", "k_fr_filter", "k_fr_refine"):
+        m = re.search(r"(k_fr_filter_q8|k_fr_filter|k_fr_refine|k_ws_build|k_fr_build|k_ws|k_rows|k_vs|k_finalize|k_mc|k_batch_rows)", k)
+        if m and m.group(1) in ("k_ws", "k_rows", "k_vs", "k_fr_filter_q8", "k_fr_filter", "k_fr_refine", "k_mc", "k_batch_rows"):
             agg[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in agg.items():
     print("==", k)

@@ -62,11 +62,8 @@ struct canopy_ctx {
 
 struct canopy_dag {
     int device = 0;
-    int32_t n_events = 0, n_gates = 0, n_levels = 0, top = 0;
-    int32_t* d_gate_type = nullptr;  // level-ordered
-    int32_t* d_gate_min = nullptr;
-    int32_t* d_gate_node = nullptr;  // output node id of the k-th level-ordered gate
-    int32_t* d_arg_ptr = nullptr;    // [n_gates+1], level-ordered
+    int32_t n_events = 0, n_gates = 0, n_levels = 0, top = 0, n_args = 0, vote_planes = 6, n_slots = 0;
+    int4* d_desc = nullptr;          // level-ordered gates: {type | K << 8, output node id, arg begin, arg end}
     int32_t* d_args = nullptr;
     int32_t* d_level_ptr = nullptr;  // [n_levels+1] into the level-ordered gate list
     uint64_t* d_thresh = nullptr;    // [n_events] ceil(p * 2^53)

@@ -292,10 +292,22 @@ static void* mc_worker(void* arg) {
     int64_t hits = 0;
     for (int64_t w = j->w0; w < j->w1; ++w) {
         for (int32_t ev = 0; ev < j->n_events; ++ev) {
-            uint64_t ek = mix64(j->key ^ (uint64_t)ev), word = 0;
-            for (int l = 0; l < 64; ++l) {
-                uint64_t n = (uint64_t)(j->first_word + w) * 64u + (uint64_t)l;
-                if ((mix64(ek + n) >> 11) < j->thresh[ev]) word |= (uint64_t)1 << l;
+            /* Sample l of this 64-sample word owns a 53-bit uniform u_l whose bit (52 - k) is bit l of the
+               "plane" R_k = mix64(ek + 64 * word_index + k), k = 0 (most significant) .. 52; the sample is
+               TRUE iff u_l < thresh (thresh = ceil(p * 2^53) <= 2^53). Evaluated here per sample, most
+               significant bit first, planes hashed on demand (the GPU kernel resolves all 64 samples of a
+               plane at once with bit masks: a different evaluation of the same definition). */
+            const uint64_t ek = mix64(j->key ^ (uint64_t)ev), T = j->thresh[ev];
+            const uint64_t base = ek + (uint64_t)(j->first_word + w) * 64u;
+            uint64_t plane[53], word = 0;
+            int n_planes = 0;
+            if (T >> 53) word = ~(uint64_t)0; /* p == 1: every u < 2^53 */
+            else for (int l = 0; l < 64; ++l) {
+                for (int k = 0; k < 53; ++k) {
+                    if (k == n_planes) { plane[k] = mix64(base + (uint64_t)k); ++n_planes; }
+                    const unsigned ub = (unsigned)((plane[k] >> l) & 1u), tb = (unsigned)((T >> (52 - k)) & 1u);
+                    if (ub != tb) { if (ub < tb) word |= (uint64_t)1 << l; break; }
+                } /* all 53 bits equal: u == thresh, not below it */
             }
             node[ev] = word;
         }
