@@ -134,6 +134,7 @@ SIGNATURES = {
     "canopy_ft_cut_sets": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
                                      C.c_void_p]),
     "canopy_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "canopy_last_kernel_variant": (C.c_int32, [C.c_void_p]),
     "canopy_timing_begin": (C.c_int, [C.c_void_p, C.c_int32]),
     "canopy_timing_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int32)]),

@@ -164,6 +164,8 @@ void canopy_ctx_free(canopy_ctx* ctx) {
     if (ctx->d_keep_mask) (void)hipFree(ctx->d_keep_mask);
     if (ctx->d_fr_count) (void)hipFree(ctx->d_fr_count);
     if (ctx->h_fr_count) (void)hipHostFree(ctx->h_fr_count);
+    if (ctx->d_fr_list) (void)hipFree(ctx->d_fr_list);
+    if (ctx->d_fr_cnt) (void)hipFree(ctx->d_fr_cnt);
     if (ctx->d_mc_hits) (void)hipFree(ctx->d_mc_hits);
     if (ctx->h_mc_hits) (void)hipHostFree(ctx->h_mc_hits);
     for (auto ev : ctx->ev_mc) if (ev) (void)hipEventDestroy(ev);
@@ -182,6 +184,8 @@ canopy_status canopy_ctx_synchronize(canopy_ctx* ctx) {
 }
 
 void* canopy_ctx_partials_device(canopy_ctx* ctx) { return ctx ? ctx->d_partial : nullptr; }
+
+int32_t canopy_last_kernel_variant(const canopy_ctx* ctx) { return ctx ? ctx->last_variant : 0; }
 
 canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* device_buffer, int32_t world_size, int32_t rank) {
     if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
@@ -315,7 +319,7 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
     info->device_bytes = m->device_bytes;
     info->stream_bytes = 0;
     if (m->fr_state == 1)
-        info->stream_bytes = m->fr_total_chunks * 1024 + (m->n_fr_slabs + 1) * 8 + (m->n_rows + 63) / 64 * 16 +
+        info->stream_bytes = m->fr_total_chunks * 1024 + (m->n_fr_slabs + 1) * 8 + m->n_fr_slabs * 8 +
                              (int64_t)m->n_events * 8;
     else if (m->vs_state == 1)
         info->stream_bytes = m->vs_total_chunks * 1024 + (m->n_slabs + 1) * 16 + (m->n_rows + 1) * 8 + (int64_t)m->n_events * 8;
@@ -346,6 +350,7 @@ canopy_status canopy_model_set_probabilities(canopy_ctx* ctx, canopy_model* m, c
         HIP_TRY(ctx, hipMemcpyAsync(m->d_logp, logp.data(), sizeof(double) * (size_t)m->n_events, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // logp is a stack-lifetime buffer
     m->has_p = true;
+    ++m->logp_version; // derived tables (the quantised filter table) are stale now
     return CANOPY_OK;
 }
 
@@ -450,7 +455,8 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         m->n_events >= 1 && m->n_events <= fr_max_events() &&
         m->n_rows >= (variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)8000000 : (int64_t)1000000) &&
         (variant == CANOPY_KERNEL_WAVE_STREAM || variant == CANOPY_KERNEL_ROWS_LDS) &&
-        !(ctx->fr_known_id == m->id && ctx->fr_known_fraction > 0.2)) {
+        !(ctx->fr_known_id == m->id && ctx->fr_known_fraction > 0.2 && ctx->fr_known_cut_off == params->cut_off &&
+          ctx->fr_known_version == m->logp_version)) {
         canopy_status pst = build_fr(ctx, const_cast<canopy_model*>(m));
         if (pst != CANOPY_OK) return pst;
         if (m->fr_state == 1) variant = CANOPY_KERNEL_FILTER_REFINE;
@@ -495,7 +501,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         ctx->row_logp_cap = m->n_rows;
     }
     const int64_t n_words = (m->n_rows + 63) / 64;
-    if ((want_mask || variant == CANOPY_KERNEL_FILTER_REFINE) && ctx->keep_mask_cap < n_words) {
+    if (want_mask && ctx->keep_mask_cap < n_words) {
         if (ctx->d_keep_mask) (void)hipFree(ctx->d_keep_mask);
         ctx->d_keep_mask = nullptr; ctx->keep_mask_cap = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_keep_mask, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1)));
@@ -539,24 +545,47 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         // delta covers the rounding difference between the unordered pass-A sum and the CSR-order sum
         const double cand_cut = a.log_cut - (1e-9 + 1e-11 * (double)m->max_row_len);
         if (!ctx->d_fr_count) {
-            HIP_TRY(ctx, hipMalloc(&ctx->d_fr_count, sizeof(unsigned long long)));
+            HIP_TRY(ctx, hipMalloc(&ctx->d_fr_count, 2 * sizeof(unsigned long long)));
             HIP_TRY(ctx, hipHostMalloc(&ctx->h_fr_count, sizeof(unsigned long long)));
+            // cleared once: the pass's final-reduce kernel leaves the accumulator at zero for the next pass
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_fr_count, 0, 2 * sizeof(unsigned long long), ctx->stream));
         }
-        if (!fr_filter_is_quantised(m->n_events)) // (the quantised path clears the counter in its table kernel)
-            HIP_TRY(ctx, hipMemsetAsync(ctx->d_fr_count, 0, sizeof(unsigned long long), ctx->stream));
         ctx->fr_pending_id = m->id;
         ctx->fr_pending_rows = m->n_rows;
+        ctx->fr_pending_cut_off = params->cut_off;
+        ctx->fr_pending_version = m->logp_version;
+        const int slab_rows = fr_slab_rows(m->n_events);
+        const int64_t list_len = m->n_fr_slabs * slab_rows;
+        if (ctx->fr_list_cap < list_len || !ctx->d_fr_list) {
+            if (ctx->d_fr_list) (void)hipFree(ctx->d_fr_list);
+            ctx->d_fr_list = nullptr; ctx->fr_list_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_fr_list, sizeof(uint16_t) * (size_t)(list_len > 0 ? list_len : 1)));
+            ctx->fr_list_cap = list_len;
+        }
+        if (ctx->fr_cnt_cap < m->n_fr_slabs || !ctx->d_fr_cnt) {
+            if (ctx->d_fr_cnt) (void)hipFree(ctx->d_fr_cnt);
+            ctx->d_fr_cnt = nullptr; ctx->fr_cnt_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_fr_cnt, sizeof(unsigned) * (size_t)(m->n_fr_slabs > 0 ? m->n_fr_slabs : 1)));
+            ctx->fr_cnt_cap = m->n_fr_slabs;
+        }
+        if (want_mask) // the refine pass ORs the exact keep bits into a cleared mask
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
         if (fr_filter_is_quantised(m->n_events)) {
             canopy_model* mm = const_cast<canopy_model*>(m);
             if (!mm->d_q8) HIP_TRY(ctx, hipMalloc(&mm->d_q8, (((size_t)m->n_events + 15) / 16) * 16 + 16));
+            // the 8-bit table depends on (logp, cut-off) only: rebuilt when either changed
+            const bool table_valid = mm->q8_version == m->logp_version && mm->q8_version != 0 && mm->q8_log_cut == a.log_cut;
             HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, mm->d_q8, m->n_rows,
-                                             m->n_events, m->n_fr_slabs, a.log_cut, ctx->d_keep_mask, ctx->d_fr_count,
-                                             ctx->n_cu, ctx->stream));
+                                             m->n_events, m->n_fr_slabs, a.log_cut, ctx->d_fr_list, ctx->d_fr_cnt, ctx->d_fr_count,
+                                             ctx->n_cu, table_valid, ctx->stream));
+            mm->q8_version = m->logp_version;
+            mm->q8_log_cut = a.log_cut;
         } else
         HIP_TRY(ctx, launch_fr_filter(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, m->n_rows,
-                                      m->n_events, m->n_fr_slabs, cand_cut, ctx->d_keep_mask, ctx->d_fr_count, ctx->n_cu,
+                                      m->n_events, m->n_fr_slabs, cand_cut, ctx->d_fr_list, ctx->d_fr_cnt, ctx->d_fr_count, ctx->n_cu,
                                       ctx->stream));
-        HIP_TRY(ctx, launch_fr_refine(a, ctx->d_keep_mask, n_words, want_mask ? 1 : 0, grid, ctx->stream));
+        HIP_TRY(ctx, launch_fr_refine(a, ctx->d_fr_list, ctx->d_fr_cnt, slab_rows, m->n_fr_slabs,
+                                      want_mask ? ctx->d_keep_mask : nullptr, grid, ctx->stream));
     } else if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
         HIP_TRY(ctx, launch_vs_kernel(a, m->d_vs_stream, m->d_vs_off, m->d_vs_slab_row, m->vs_total_chunks, m->n_slabs,
                                       grid, ctx->stream));
@@ -569,7 +598,8 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     }
     HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     HIP_TRY(ctx, launch_finalize(ctx->d_block_partials, n_records, ctx->d_partial, ctx->d_gather, ctx->gather_world,
-                                 ctx->gather_rank, ctx->stream));
+                                 ctx->gather_rank, variant == CANOPY_KERNEL_FILTER_REFINE ? ctx->d_fr_count : nullptr, ctx->stream));
+    ctx->last_variant = variant;
     HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     if (ev == ctx->ev_last) ctx->last_timed = true;
     ctx->last_has_row_logp = want_rows;
@@ -583,12 +613,14 @@ canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* out) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, ctx->d_partial, sizeof(double) * CANOPY_PARTIAL_DOUBLES,
                                 hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->fr_pending_id)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fr_count, ctx->d_fr_count, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fr_count, ctx->d_fr_count + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                     ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out, ctx->h_partial, sizeof(canopy_partial));
     if (ctx->fr_pending_id) { // feedback for AUTO: a filter that flags most rows is not worth its refine pass
         ctx->fr_known_id = ctx->fr_pending_id;
+        ctx->fr_known_cut_off = ctx->fr_pending_cut_off;
+        ctx->fr_known_version = ctx->fr_pending_version;
         ctx->fr_known_fraction = ctx->fr_pending_rows > 0 ? (double)*ctx->h_fr_count / (double)ctx->fr_pending_rows : 0.0;
         ctx->fr_pending_id = 0;
     }

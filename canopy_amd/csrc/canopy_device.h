@@ -156,6 +156,45 @@ __device__ __forceinline__ void fold_kept_rows(CSum& rare, CSum& l1p, double& n_
     for (int u = 0; u < N; ++u) fold_terms(rare, l1p, n_certain, P[u], l[u], on[u]);
 }
 
+// Deterministic final reduce of n per-workgroup records by ONE 256-thread workgroup: fixed thread <- record
+// assignment, fixed tree. Output is the canopy_partial layout (hi/lo renormalised); with a gather buffer the
+// record also goes into slot `rank` and zeros into the other slots (K5: one sum all-reduce = all-gather).
+// s_red: 4 * kAccDoubles doubles, s_out: kAccDoubles doubles of LDS.
+__device__ __forceinline__ void finalize_records(const double* __restrict__ parts, int n, double* out, double* gather,
+                                                 int world, int rank, double* s_red, double* s_out) {
+    Acc acc;
+    acc_init(acc);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        Acc o;
+        acc_load(o, parts + (size_t)i * kAccDoubles);
+        acc_merge(acc, o);
+    }
+    acc_wave_reduce(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) acc_store(s_red + wave * kAccDoubles, acc);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Acc t;
+        acc_load(t, s_red);
+        for (int w = 1; w < 4; ++w) {
+            Acc o;
+            acc_load(o, s_red + w * kAccDoubles);
+            acc_merge(t, o);
+        }
+        const double rh = t.rare.s + t.rare.c;
+        const double rl = (t.rare.s - rh) + t.rare.c;
+        const double lh = t.l1p.s + t.l1p.c;
+        const double ll = (t.l1p.s - lh) + t.l1p.c;
+        s_out[0] = rh; s_out[1] = rl; s_out[2] = lh; s_out[3] = ll;
+        s_out[4] = t.n_kept; s_out[5] = t.n_certain; s_out[6] = t.max_logp; s_out[7] = t.argmax;
+    }
+    __syncthreads();
+    if (threadIdx.x < kAccDoubles) out[threadIdx.x] = s_out[threadIdx.x];
+    if (gather != nullptr)
+        for (int i = threadIdx.x; i < world * kAccDoubles; i += 256)
+            gather[i] = (i / kAccDoubles == rank) ? s_out[i % kAccDoubles] : 0.0;
+}
+
 // Per-row epilogue shared by every row kernel: filter, P = exp(s), both sums, argmax.
 __device__ __forceinline__ bool row_epilogue(Acc& a, double s, int len, bool valid, double log_cut,
                                             int limit_order, double global_row) {

@@ -43,12 +43,18 @@ struct canopy_ctx {
     bool timing_on = false;
 
     // FILTER_REFINE: candidates flagged by the last filter pass (device counter, pinned mirror)
-    unsigned long long* d_fr_count = nullptr;
+    unsigned long long* d_fr_count = nullptr; // [2]: accumulator of the running filter pass, total of the last finished pass
+    int32_t last_variant = 0;                 // CANOPY_KERNEL_* the last quantify pass ran
     unsigned long long* h_fr_count = nullptr;
+    uint16_t* d_fr_list = nullptr;  // [n_slabs * slab_rows] per-slab candidate lists (local row ids) of the last filter pass
+    unsigned* d_fr_cnt = nullptr;   // [n_slabs] their lengths
+    int64_t fr_list_cap = 0, fr_cnt_cap = 0;
     uint64_t fr_pending_id = 0;   // model id whose filter count is still on the device (0 = none)
     int64_t fr_pending_rows = 0;
     uint64_t fr_known_id = 0;     // last model id with a known candidate fraction
     double fr_known_fraction = -1.0;
+    double fr_known_cut_off = -1.0, fr_pending_cut_off = -1.0; // the feedback applies to the same (model, p, cut-off) only
+    uint64_t fr_known_version = 0, fr_pending_version = 0;
     // K6 Monte-Carlo
     unsigned long long* d_mc_hits = nullptr; // [1]
     unsigned long long* h_mc_hits = nullptr; // pinned
@@ -79,6 +85,9 @@ struct canopy_model {
     int32_t* d_col_idx = nullptr; // [nnz] (+ 16 B of slack for 16-byte slab loads)
     double* d_logp = nullptr;     // [n_events]
     uint8_t* d_q8 = nullptr;      // [n_events rounded up to 16] quantised -logp of the FILTER_REFINE filter pass
+    uint64_t logp_version = 0;    // bumped whenever d_logp's contents (or the pointer) change
+    uint64_t q8_version = 0;      // logp_version the table in d_q8 was built from (0 = none)
+    double q8_log_cut = 0.0;      // ... and the log cut-off it was built for
     bool has_p = false;
     int64_t device_bytes = 0;
     // derived wave-slab stream layout (kernels_ws.hip), built by canopy_model_prepare
@@ -119,8 +128,10 @@ struct RowKernelArgs {
 int rows_kernel_default_grid(int n_cu, int variant, int64_t n_rows);
 size_t rows_lds_table_limit_events();
 hipError_t launch_rows_kernel(int variant, const RowKernelArgs& a, int grid, hipStream_t s);
+// fr_count: null, or the FILTER_REFINE candidate counter pair -- [0] (accumulated by the filter) is handed
+// over to [1] (read by the host) and cleared for the next pass
 hipError_t launch_finalize(const double* block_partials, int n_blocks, double* out, double* gather,
-                           int world, int rank, hipStream_t s);
+                           int world, int rank, unsigned long long* fr_count, hipStream_t s);
 
 // kernels_build.hip
 hipError_t launch_validate_csr(const int64_t* row_ptr, const int32_t* col_idx, int64_t n_rows,
@@ -162,14 +173,16 @@ int fr_refine_grid(int n_cu);
 hipError_t fr_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events,
                     int32_t max_row_len, uint32_t** d_stream_out, int64_t** d_fr_off_out, int64_t* total_chunks_out,
                     int64_t* n_slabs_out, bool* ok, hipStream_t s);
+int fr_slab_rows(int32_t n_events);
 hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
-                            int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint64_t* cand_mask,
-                            unsigned long long* cand_count, int n_cu, hipStream_t s);
+                            int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint16_t* cand_list,
+                            unsigned* cand_cnt, unsigned long long* cand_count, int n_cu, hipStream_t s);
 bool fr_filter_is_quantised(int32_t n_events);
 hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
                                uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs, double log_cut,
-                               uint64_t* cand_mask, unsigned long long* cand_count, int n_cu, hipStream_t s);
-hipError_t launch_fr_refine(const RowKernelArgs& a, uint64_t* mask, int64_t n_words, int write_mask, int grid,
-                            hipStream_t s);
+                               uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count, int n_cu,
+                               bool table_valid, hipStream_t s);
+hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, const unsigned* cand_cnt, int slab_rows,
+                            int64_t n_slabs, uint64_t* keep_mask, int grid, hipStream_t s);
 
 } // namespace canopy

@@ -375,12 +375,14 @@ canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* m, cons
     const bool was_timing = ctx->timing_on;
     m->d_logp = b->d_logp_max;
     m->has_p = true;
+    ++m->logp_version; // the filter's quantised table must be rebuilt for the envelope ...
     ctx->timing_on = false;
     canopy_status st = canopy_quantify_async(ctx, m, &cprm);
     canopy_partial env;
     if (st == CANOPY_OK) st = canopy_quantify_fetch(ctx, &env);
     m->d_logp = saved_logp;
     m->has_p = saved_has_p;
+    ++m->logp_version; // ... and again for the model's own probabilities
     ctx->timing_on = was_timing;
     if (st != CANOPY_OK) return st;
     const int64_t n_c = (int64_t)env.n_kept;

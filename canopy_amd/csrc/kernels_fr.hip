@@ -12,7 +12,8 @@
 //           wave takes any chunk: 64 gathers of neighbouring columns, then 64 unordered ds_add_f64.
 //           The order of additions is NOT the CSR order here, so s~_i differs from s_i by rounding only
 //           (<= len * 2^-53 * sum|logp|, about 1e-13). Rows with s~_i >= log(cut_off) - delta
-//           (delta = 1e-9 >> that error) are flagged in a candidate bitmask.
+//           (delta = 1e-9 >> that error) go into the slab's candidate list (u16 local row ids, ascending,
+//           positions from an in-workgroup prefix scan of the ballots: deterministic).
 //   pass B  k_fr_refine: every candidate row is recomputed from the canonical CSR in exact CSR order
 //           (the same plain v_add_f64 chain as the oracle) and goes through the exact filter, exp / log1p
 //           sums, count, argmax, keep mask. No row that survives exactly can be missed (its s~ is within
@@ -50,7 +51,7 @@ struct FrCfg {
 
 // 16384-row slabs (one 16-wave workgroup per CU) measured faster than 8192-row slabs (two 8-wave
 // workgroups): 0.85 vs 0.98 ms at config 3. They need 15 row bits, i.e. E <= 2^17; beyond that 8192.
-constexpr int kQ8MaxEvents = 112 * 1024; // 8-bit table + 8192 u32 row sums must fit the 160 KiB of LDS
+constexpr int kQ8MaxEvents = 112 * 1024; // 8-bit table + 8192 u32 row sums + 128 counts must fit the 160 KiB of LDS
 constexpr int kQ8Levels = 224;           // threshold level; entries clamp at 255 (alone enough to kill a row)
 
 bool fr_use_q8(int32_t n_events) {
@@ -126,13 +127,50 @@ __device__ __forceinline__ void fr_barrier() { // LDS drained, then the workgrou
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ---- candidate emission (shared by both filters) --------------------------------------------------------
+// After the row sums of a slab are final, thread tid holds the ballots m[i] of rows i * THREADS + tid,
+// i < NI. The candidates of the slab are written to its list segment in ascending row order = (i, wave,
+// lane) order: every wave publishes popcount(m[i]) to s_cnt[i * NW + wave], one workgroup barrier, every
+// wave scans all NI * NW counts and writes its own candidates. Positions never depend on timing.
+template <int NI, int NW>
+__device__ __forceinline__ unsigned fr_emit_candidates(const unsigned long long (&m)[NI], const unsigned* s_cnt, int lane,
+                                                       int wave, int tid, uint16_t* __restrict__ seg) {
+    constexpr int NC = NI * NW, PER = NC / kWave;
+    static_assert(NC % kWave == 0 && (PER == 2 || PER == 4), "counts per lane");
+    unsigned c[PER], offs[PER], tot = 0;
+#pragma unroll
+    for (int p = 0; p < PER; ++p) { c[p] = s_cnt[lane * PER + p]; tot += c[p]; }
+    unsigned incl = tot;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += o;
+    }
+    offs[0] = incl - tot;
+#pragma unroll
+    for (int p = 1; p < PER; ++p) offs[p] = offs[p - 1] + c[p - 1];
+    const unsigned total = __shfl(incl, kWave - 1, kWave);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = i * NW + wave; // wave-uniform
+        unsigned sel = offs[0];
+#pragma unroll
+        for (int p = 1; p < PER; ++p) sel = (idx % PER) == p ? offs[p] : sel;
+        const unsigned off = __shfl(sel, idx / PER, kWave);
+        if ((m[i] >> lane) & 1ULL)
+            seg[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[i], 0u))] =
+                (uint16_t)(i * (NW * kWave) + tid);
+    }
+    return total;
+}
+
 // ---- pass A ------------------------------------------------------------------------------------------
 template <int SLAB_ROWS, int kFrU>
 __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const uint4* __restrict__ stream,
                                                              const int64_t* __restrict__ fr_off, int64_t total_chunks,
                                                              const double* __restrict__ logp, int64_t n_rows,
                                                              int64_t n_slabs, double cand_cut,
-                                                             uint64_t* __restrict__ cand_mask,
+                                                             uint16_t* __restrict__ cand_list, unsigned* __restrict__ cand_cnt,
                                                              unsigned long long* __restrict__ cand_count) {
     using Cf = FrCfg<SLAB_ROWS>;
     constexpr int kFrRowBits = Cf::row_bits, kFrSlabRows = Cf::slab_rows, kFrSlots = Cf::slots, kFrWaves = Cf::waves,
@@ -140,6 +178,7 @@ __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const u
     constexpr uint32_t kFrRowMask = Cf::row_mask;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sums = reinterpret_cast<double*>(smem);
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(smem + Cf::lds); // [slab_rows / 64] candidate counts
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -182,27 +221,30 @@ __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const u
             for (int u = 0; u < kFrU; ++u) q[u] = qn[u];
         }
         fr_barrier();
-        // -------- phase 2: flag the rows that might survive, clear the sums
+        // -------- phase 2: list the rows that might survive, clear the sums
         const int64_t r0 = s * kFrSlabRows;
-#pragma unroll 4
-        for (int i = 0; i < kFrSlabRows / kFrThreads; ++i) {
+        constexpr int NI = kFrSlabRows / kFrThreads;
+        unsigned long long m[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
             const int rl = i * kFrThreads + tid;
             const double sv = sums[rl];
             sums[rl] = 0.0;
-            const int64_t r = r0 + rl;
-            const unsigned long long m = __ballot(r < n_rows && sv >= cand_cut);
-            if (lane == 0 && r < n_rows) cand_mask[r >> 6] = m;
-            n_cand += (unsigned long long)__builtin_popcountll(m);
+            m[i] = __ballot(r0 + rl < n_rows && sv >= cand_cut);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) s_cnt[i * kFrWaves + wave] = (unsigned)__builtin_popcountll(m[i]);
         }
         if (tid < 64) sums[kFrSlabRows + tid] = 0.0; // the sink
         fr_barrier();
+        const unsigned total = fr_emit_candidates<NI, kFrWaves>(m, s_cnt, lane, wave, tid, cand_list + s * kFrSlabRows);
+        if (tid == 0) cand_cnt[s] = total;
+        n_cand += total; // wave-uniform
     }
-    // The count lets the host see when the filter stops paying off. One global atomic per block (thousands
-    // of same-address atomics, one per wave, cost ~50 us); n_cand is wave-uniform, the sink is zero here.
-    unsigned long long* block_cand = reinterpret_cast<unsigned long long*>(sums + kFrSlabRows);
-    if (lane == 0 && n_cand) __hip_atomic_fetch_add(block_cand, n_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    fr_barrier();
-    if (tid == 0 && *block_cand) atomicAdd(cand_count, *block_cand);
+    // The count lets the host see when the filter stops paying off: one global atomic per workgroup
+    // (one per wave -- thousands of same-address atomics -- cost ~50 us). n_cand is workgroup-uniform.
+    if (tid == 0 && n_cand) atomicAdd(cand_count, n_cand);
 }
 
 // ---- pass A, quantised form ---------------------------------------------------------------------------
@@ -214,9 +256,8 @@ __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const u
 // the fp64 filter at ~33 clk per 64 lanes), only ds_read_u8 + ds_add_u32, and the TA just streams.
 // The price is a looser bound (about 0.08 per entry in log units): more candidates for the exact pass B.
 __global__ __launch_bounds__(256) void k_fr_q8_table(const double* __restrict__ logp, int32_t n_events, double inv_step,
-                                                     uint8_t* __restrict__ q8, unsigned long long* cand_count) {
+                                                     uint8_t* __restrict__ q8) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == 0) *cand_count = 0ULL; // the filter kernel behind this one counts its candidates here
     if (j >= n_events) return;
     const double neg = -logp[j]; // >= 0, +inf for p = 0
     // (1 - 2^-30): the bound must stay a lower bound although (a) the product may round up across an
@@ -235,11 +276,12 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
                                                              const int64_t* __restrict__ fr_off, int64_t total_chunks,
                                                              const uint8_t* __restrict__ q8, int32_t n_events,
                                                              int64_t n_rows, int64_t n_slabs, int threshold,
-                                                             uint64_t* __restrict__ cand_mask,
+                                                             uint16_t* __restrict__ cand_list, unsigned* __restrict__ cand_cnt,
                                                              unsigned long long* __restrict__ cand_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* sums = reinterpret_cast<unsigned*>(smem);
     uint8_t* tab = reinterpret_cast<uint8_t*>(smem + kQ8SumsBytes);
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(smem + kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16); // [128]
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -283,34 +325,33 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
         }
         fr_barrier();
         const int64_t r0 = s * kQ8SlabRows;
-#pragma unroll 4
-        for (int i = 0; i < kQ8SlabRows / kQ8Threads; ++i) {
+        constexpr int NI = kQ8SlabRows / kQ8Threads;
+        unsigned long long m[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
             const int rl = i * kQ8Threads + tid;
             const int sv = (int)sums[rl];
             sums[rl] = 0u;
-            const int64_t r = r0 + rl;
-            const unsigned long long m = __ballot(r < n_rows && sv <= threshold);
-            if (lane == 0 && r < n_rows) cand_mask[r >> 6] = m;
-            n_cand += (unsigned long long)__builtin_popcountll(m);
+            m[i] = __ballot(r0 + rl < n_rows && sv <= threshold);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) s_cnt[i * kQ8Waves + wave] = (unsigned)__builtin_popcountll(m[i]);
         }
         if (tid < 64) sums[kQ8SlabRows + tid] = 0u; // the sink
         fr_barrier();
+        const unsigned total = fr_emit_candidates<NI, kQ8Waves>(m, s_cnt, lane, wave, tid, cand_list + s * kQ8SlabRows);
+        if (tid == 0) cand_cnt[s] = total;
+        n_cand += total; // workgroup-uniform
     }
-    // one global atomic per block, as in k_fr_filter
-    // (n_cand is wave-uniform; the sink words are zero again here and 8-byte aligned)
-    unsigned long long* block_cand = reinterpret_cast<unsigned long long*>(sums + kQ8SlabRows);
-    if (lane == 0 && n_cand) __hip_atomic_fetch_add(block_cand, n_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    fr_barrier();
-    if (tid == 0 && *block_cand) atomicAdd(cand_count, *block_cand);
+    if (tid == 0 && n_cand) atomicAdd(cand_count, n_cand); // one global atomic per workgroup, as in k_fr_filter
 }
 
 // ---- pass B ------------------------------------------------------------------------------------------
-// A wave takes 64 consecutive mask words (4096 rows), compacts their candidate bits into an LDS list
-// (wave-level prefix sum of the popcounts) and recomputes the candidates 64 at a time: each lane sums one
-// candidate row from the canonical CSR in CSR order. Fixed wave <- words and lane <- candidate
-// assignment => reproducible. Exact keep bits are collected per word in LDS and written back in place.
+// Two waves per slab walk its candidate list, 64 candidates per trip each: a lane sums one candidate row
+// from the canonical CSR in CSR order. Fixed wave <- (slab, half) and lane <- list position assignment =>
+// reproducible. The exact keep bits are OR-ed into a pre-cleared mask when the caller wants one.
 constexpr int kRefineWaves = 4;
-constexpr int kRefineCap = 1024; // candidates a wave can compact per 4096 rows; beyond that: per-lane walk
 
 __device__ __forceinline__ double refine_row_sum(const RowKernelArgs& a, int64_t r, int* len_out) {
     const int64_t b = a.row_ptr[r], e = a.row_ptr[r + 1];
@@ -330,71 +371,33 @@ __device__ __forceinline__ double refine_row_sum(const RowKernelArgs& a, int64_t
     return s;
 }
 
-__global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArgs a, uint64_t* __restrict__ mask /* in: candidates, out: keep */,
-                                                                   int64_t n_words, int write_mask) {
+__global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArgs a, const uint16_t* __restrict__ cand_list,
+                                                                   const unsigned* __restrict__ cand_cnt, int slab_rows,
+                                                                   int64_t n_slabs, uint64_t* __restrict__ keep_mask) {
     __shared__ double s_red[kRefineWaves * kAccDoubles];
-    __shared__ unsigned short s_list[kRefineWaves][kRefineCap];
-    __shared__ unsigned long long s_keep[kRefineWaves][kWave];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    unsigned short* list = s_list[wave];
-    unsigned long long* keepw = s_keep[wave];
     Acc acc;
     acc_init(acc);
     const int64_t GW = (int64_t)gridDim.x * kRefineWaves;
-    for (int64_t w0 = ((int64_t)blockIdx.x * kRefineWaves + wave) * kWave; w0 < n_words; w0 += GW * kWave) {
-        const int64_t w = w0 + lane;
-        const unsigned long long m = w < n_words ? mask[w] : 0ULL;
-        // inclusive wave scan of the candidate counts
-        const int cnt = __builtin_popcountll(m);
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const int o = __shfl_up(incl, d, kWave);
-            if (lane >= d) incl += o;
-        }
-        const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
-        if (total == 0) continue; // mask words are already zero
-        if (total <= kRefineCap) {
-            int k = incl - cnt;
-            for (unsigned long long mm = m; mm != 0ULL; mm &= mm - 1)
-                list[k++] = (unsigned short)(lane * 64 + __builtin_ctzll(mm));
-            keepw[lane] = 0ULL;
-            for (int j0 = 0; j0 < total; j0 += kWave) {
-                const bool on = j0 + lane < total;
-                const int ro = on ? (int)list[j0 + lane] : 0;
-                const int64_t r = w0 * 64 + ro;
-                int len = 0;
-                const double s = on ? refine_row_sum(a, r, &len) : 0.0;
-                const bool keep = on && (s >= a.log_cut) && (a.limit_order == 0 || len <= a.limit_order);
-                fold_kept_row(acc.rare, acc.l1p, acc.n_certain, s, keep);
-                if (keep) {
-                    acc.n_kept += 1.0;
-                    // rows arrive in ascending order per lane, ties resolve to the lower row in acc_merge
-                    if (s > acc.max_logp) { acc.max_logp = s; acc.argmax = (double)(a.row_offset + r); }
-                    if (write_mask) atomicOr(&keepw[ro >> 6], 1ULL << (ro & 63));
-                }
+    for (int64_t u = (int64_t)blockIdx.x * kRefineWaves + wave; u < 2 * n_slabs; u += GW) {
+        const int64_t s = u >> 1;
+        const int n = (int)__builtin_amdgcn_readfirstlane(cand_cnt[s]);
+        const int64_t base = s * slab_rows;
+        for (int j0 = (int)(u & 1) * kWave; j0 < n; j0 += 2 * kWave) {
+            const bool on = j0 + lane < n;
+            const int64_t r = base + (on ? (int64_t)cand_list[base + j0 + lane] : 0);
+            int len = 0;
+            const double sv = on ? refine_row_sum(a, r, &len) : 0.0;
+            const bool keep = on && (sv >= a.log_cut) && (a.limit_order == 0 || len <= a.limit_order);
+            fold_kept_row(acc.rare, acc.l1p, acc.n_certain, sv, keep);
+            if (keep) {
+                acc.n_kept += 1.0;
+                // rows arrive in ascending order per lane, ties resolve to the lower row in acc_merge
+                if (sv > acc.max_logp) { acc.max_logp = sv; acc.argmax = (double)(a.row_offset + r); }
+                if (keep_mask != nullptr) atomicOr(reinterpret_cast<unsigned long long*>(&keep_mask[r >> 6]), 1ULL << (r & 63));
             }
-            if (write_mask && w < n_words) mask[w] = keepw[lane];
-        } else { // a dense window: each lane walks its own word
-            unsigned long long keep_bits = 0ULL;
-            for (unsigned long long mm = m; mm != 0ULL; mm &= mm - 1) {
-                const int bit = __builtin_ctzll(mm);
-                const int64_t r = w * 64 + bit;
-                int len = 0;
-                const double s = refine_row_sum(a, r, &len);
-                const bool keep = (s >= a.log_cut) && (a.limit_order == 0 || len <= a.limit_order);
-                if (keep) {
-                    keep_bits |= 1ULL << bit;
-                    const double P = exp(s);
-                    csum_add(acc.rare, P);
-                    if (P < 1.0) csum_add(acc.l1p, log1p(-P)); else acc.n_certain += 1.0;
-                    acc.n_kept += 1.0;
-                    if (s > acc.max_logp) { acc.max_logp = s; acc.argmax = (double)(a.row_offset + r); }
-                }
-            }
-            if (write_mask && w < n_words) mask[w] = keep_bits;
         }
     }
     acc_wave_reduce(acc);
@@ -417,6 +420,7 @@ __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArg
 int fr_max_events() { return 1 << 18; }
 bool fr_filter_is_quantised(int32_t n_events) { return fr_use_q8(n_events) && fr_slab_rows_for(n_events) == 8192; }
 int fr_refine_grid(int n_cu) { return n_cu * 8; }
+int fr_slab_rows(int32_t n_events) { return fr_slab_rows_for(n_events); }
 
 hipError_t fr_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events,
                     int32_t max_row_len, uint32_t** d_stream_out, int64_t** d_fr_off_out, int64_t* total_chunks_out,
@@ -505,7 +509,7 @@ hipError_t fr_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
 namespace {
 template <int SLAB_ROWS, int U>
 hipError_t launch_fr_filter_t(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
-                              int64_t n_rows, int64_t n_slabs, double cand_cut, uint64_t* cand_mask,
+                              int64_t n_rows, int64_t n_slabs, double cand_cut, uint16_t* cand_list, unsigned* cand_cnt,
                               unsigned long long* cand_count, int n_cu, hipStream_t s) {
     using Cf = FrCfg<SLAB_ROWS>;
     static bool attr_set = false;
@@ -518,44 +522,48 @@ hipError_t launch_fr_filter_t(const uint32_t* stream, const int64_t* fr_off, int
     int64_t grid = (int64_t)n_cu * (SLAB_ROWS > 8192 ? 1 : 2);
     if (grid > n_slabs) grid = n_slabs;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_fr_filter<SLAB_ROWS, U>), dim3((unsigned)grid), dim3(Cf::threads), Cf::lds, s,
+    hipLaunchKernelGGL((k_fr_filter<SLAB_ROWS, U>), dim3((unsigned)grid), dim3(Cf::threads), Cf::lds + (SLAB_ROWS / 64) * 4, s,
                        reinterpret_cast<const uint4*>(stream), fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut,
-                       cand_mask, cand_count);
+                       cand_list, cand_cnt, cand_count);
     return hipGetLastError();
 }
 } // namespace
 
 hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
-                            int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint64_t* cand_mask,
-                            unsigned long long* cand_count, int n_cu, hipStream_t s) {
+                            int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint16_t* cand_list,
+                            unsigned* cand_cnt, unsigned long long* cand_count, int n_cu, hipStream_t s) {
     static const int u = getenv("CANOPY_FR_U") ? atoi(getenv("CANOPY_FR_U")) : 4; // tuning only
     if (fr_slab_rows_for(n_events) == 16384) {
-        if (u == 1) return launch_fr_filter_t<16384, 1>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
-        if (u == 4) return launch_fr_filter_t<16384, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
-        if (u == 2) return launch_fr_filter_t<16384, 2>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
-        return launch_fr_filter_t<16384, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
+        if (u == 1) return launch_fr_filter_t<16384, 1>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_list, cand_cnt, cand_count, n_cu, s);
+        if (u == 4) return launch_fr_filter_t<16384, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_list, cand_cnt, cand_count, n_cu, s);
+        if (u == 2) return launch_fr_filter_t<16384, 2>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_list, cand_cnt, cand_count, n_cu, s);
+        return launch_fr_filter_t<16384, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_list, cand_cnt, cand_count, n_cu, s);
     }
-    if (u == 1) return launch_fr_filter_t<8192, 1>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
-    if (u == 4) return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
-    if (u == 2) return launch_fr_filter_t<8192, 2>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
-    return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_mask, cand_count, n_cu, s);
+    if (u == 1) return launch_fr_filter_t<8192, 1>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_list, cand_cnt, cand_count, n_cu, s);
+    if (u == 4) return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_list, cand_cnt, cand_count, n_cu, s);
+    if (u == 2) return launch_fr_filter_t<8192, 2>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_list, cand_cnt, cand_count, n_cu, s);
+    return launch_fr_filter_t<8192, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_list, cand_cnt, cand_count, n_cu, s);
 }
 
-// Quantised filter: builds the 8-bit table for (logp, cut-off) and runs k_fr_filter_q8. q8_buf holds
-// n_events bytes rounded up to 16.
+// Quantised filter: builds the 8-bit table for (logp, cut-off) unless the caller says q8_buf already holds
+// it (table_valid), and runs k_fr_filter_q8. q8_buf holds n_events bytes rounded up to 16.
 hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
                                uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs, double log_cut,
-                               uint64_t* cand_mask, unsigned long long* cand_count, int n_cu, hipStream_t s) {
+                               uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count, int n_cu,
+                               bool table_valid, hipStream_t s) {
     const double mag = -log_cut > 1.0 ? -log_cut : 1.0;
     const double inv_step = (double)kQ8Levels / mag;
     // s >= log_cut  ==>  sum(q) <= -log_cut / step; (1 + 2^-28): a hair generous, never too strict
     const double t = -log_cut * inv_step * (1.0 + 0x1.0p-28);
     const int threshold = t < 0.0 ? -1 : (t > 2.0e9 ? 2000000000 : (int)t);
-    hipLaunchKernelGGL(k_fr_q8_table, dim3(grid_for(n_events, 256)), dim3(256), 0, s, logp, n_events, inv_step, q8_buf, cand_count);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (!table_valid) {
+        hipLaunchKernelGGL(k_fr_q8_table, dim3(grid_for(n_events, 256)), dim3(256), 0, s, logp, n_events, inv_step, q8_buf);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     static const int u = getenv("CANOPY_FR_QU") ? atoi(getenv("CANOPY_FR_QU")) : 2; // tuning only
-    const size_t lds = kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16;
+    const size_t lds = kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16 + (kQ8SlabRows / 64) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -567,15 +575,16 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
     int64_t grid = n_cu;
     if (grid > n_slabs) grid = n_slabs;
     if (grid < 1) grid = 1;
-#define Q8_GO(UU) hipLaunchKernelGGL(k_fr_filter_q8<UU>, dim3((unsigned)grid), dim3(kQ8Threads), lds, s, reinterpret_cast<const uint4*>(stream), fr_off, total_chunks, q8_buf, n_events, n_rows, n_slabs, threshold, cand_mask, cand_count)
+#define Q8_GO(UU) hipLaunchKernelGGL(k_fr_filter_q8<UU>, dim3((unsigned)grid), dim3(kQ8Threads), lds, s, reinterpret_cast<const uint4*>(stream), fr_off, total_chunks, q8_buf, n_events, n_rows, n_slabs, threshold, cand_list, cand_cnt, cand_count)
     if (u == 1) Q8_GO(1); else if (u == 4) Q8_GO(4); else Q8_GO(2);
 #undef Q8_GO
     return hipGetLastError();
 }
 
-hipError_t launch_fr_refine(const RowKernelArgs& a, uint64_t* mask, int64_t n_words, int write_mask, int grid,
-                            hipStream_t s) {
-    hipLaunchKernelGGL(k_fr_refine, dim3(grid), dim3(256), 0, s, a, mask, n_words, write_mask);
+hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, const unsigned* cand_cnt, int slab_rows,
+                            int64_t n_slabs, uint64_t* keep_mask, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_fr_refine, dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows, n_slabs,
+                       keep_mask);
     return hipGetLastError();
 }
 

@@ -186,44 +186,16 @@ __global__ __launch_bounds__(kRowsWaves * kWave) void k_rows(RowKernelArgs a) {
     }
 }
 
-// Deterministic final reduce of the per-workgroup records: fixed thread <- record assignment,
-// fixed tree. Output is the canopy_partial layout (hi/lo renormalised).
+// Deterministic final reduce of the per-workgroup records (finalize_records in canopy_device.h).
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ parts, int n, double* out,
-                                                  double* gather, int world, int rank) {
+                                                  double* gather, int world, int rank, unsigned long long* fr_count) {
     __shared__ double s_red[4 * kAccDoubles];
     __shared__ double s_out[kAccDoubles];
-    Acc acc;
-    acc_init(acc);
-    for (int i = threadIdx.x; i < n; i += 256) {
-        Acc o;
-        acc_load(o, parts + (size_t)i * kAccDoubles);
-        acc_merge(acc, o);
+    finalize_records(parts, n, out, gather, world, rank, s_red, s_out);
+    if (fr_count != nullptr && threadIdx.x == 0) { // FILTER_REFINE: last pass's candidate total for the host,
+        fr_count[1] = fr_count[0];                  // accumulator cleared for the next pass's filter
+        fr_count[0] = 0ULL;
     }
-    acc_wave_reduce(acc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) acc_store(s_red + wave * kAccDoubles, acc);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        Acc t;
-        acc_load(t, s_red);
-        for (int w = 1; w < 4; ++w) {
-            Acc o;
-            acc_load(o, s_red + w * kAccDoubles);
-            acc_merge(t, o);
-        }
-        const double rh = t.rare.s + t.rare.c;
-        const double rl = (t.rare.s - rh) + t.rare.c;
-        const double lh = t.l1p.s + t.l1p.c;
-        const double ll = (t.l1p.s - lh) + t.l1p.c;
-        s_out[0] = rh; s_out[1] = rl; s_out[2] = lh; s_out[3] = ll;
-        s_out[4] = t.n_kept; s_out[5] = t.n_certain; s_out[6] = t.max_logp; s_out[7] = t.argmax;
-    }
-    __syncthreads();
-    if (threadIdx.x < kAccDoubles) out[threadIdx.x] = s_out[threadIdx.x];
-    // K5: own record into slot `rank`, zeros elsewhere -> a single sum all-reduce is an all-gather
-    if (gather != nullptr)
-        for (int i = threadIdx.x; i < world * kAccDoubles; i += 256)
-            gather[i] = (i / kAccDoubles == rank) ? s_out[i % kAccDoubles] : 0.0;
 }
 
 } // namespace
@@ -259,8 +231,8 @@ hipError_t launch_rows_kernel(int variant, const RowKernelArgs& a, int grid, hip
 }
 
 hipError_t launch_finalize(const double* block_partials, int n_blocks, double* out, double* gather,
-                           int world, int rank, hipStream_t s) {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, block_partials, n_blocks, out, gather, world, rank);
+                           int world, int rank, unsigned long long* fr_count, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, block_partials, n_blocks, out, gather, world, rank, fr_count);
     return hipGetLastError();
 }
 

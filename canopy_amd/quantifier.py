@@ -132,6 +132,10 @@ class Context:
         capi.check(capi.lib().canopy_last_kernel_ms(self._h, C.byref(a), C.byref(b)), "canopy_last_kernel_ms", self._h)
         return a.value, b.value
 
+    def last_kernel_variant(self):
+        """The CANOPY_KERNEL_* id the last pass ran (what AUTO resolved to)."""
+        return capi.lib().canopy_last_kernel_variant(self._h)
+
     def timing_begin(self, max_launches):
         capi.check(capi.lib().canopy_timing_begin(self._h, max_launches), "canopy_timing_begin", self._h)
 

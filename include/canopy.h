@@ -267,6 +267,9 @@ CANOPY_API canopy_status canopy_fetch_keep_mask(canopy_ctx* ctx, const canopy_mo
  */
 CANOPY_API canopy_status canopy_last_kernel_ms(canopy_ctx* ctx, double* row_kernel_ms,
                                                double* total_ms);
+/* The CANOPY_KERNEL_* variant the last canopy_quantify_async on this context actually ran (what AUTO
+   resolved to); 0 before the first pass. */
+CANOPY_API int32_t canopy_last_kernel_variant(const canopy_ctx* ctx);
 
 /* ---- N4: batched quantification -- K probability vectors ("trials") against one model ------------- */
 /*

@@ -282,21 +282,26 @@ def test_gather_slot_buffer_single_rank(gpu_ctx, oracle):
 def test_auto_leaves_filter_refine_when_most_rows_survive(gpu_ctx, oracle):
     """AUTO feedback: with a cut-off that keeps most rows the filter flags > 20 % of them; the next AUTO
     pass on that model runs the wave-slab stream instead. Results are the oracle's either way."""
-    from canopy_amd import default_params
-    n_events = 5000
-    row_ptr, col = oracle.synth_csr(SEED, 200000, n_events, 4, n_threads=4)
+    from canopy_amd import _capi, default_params
+    n_events, n_rows = 5000, 1_200_000  # AUTO considers filter/refine from 1e6 rows on
+    row_ptr, col = oracle.synth_csr(SEED, n_rows, n_events, 4, n_threads=4)
     p = oracle.synth_probabilities(SEED, n_events)
-    want = oracle.quantify(row_ptr, col, p, cut_off=1e-30, limit_order=20)
-    assert want.n_kept > 0.5 * 200000
+    want = oracle.quantify(row_ptr, col, p, cut_off=1e-30, limit_order=20, n_threads=4, want_rows=False)
+    assert want.n_kept > 0.5 * n_rows
     model = gpu_ctx.upload(row_ptr, col, n_events)
     model.set_probabilities(p)
-    times = []
+    ran = []
     for _ in range(3):
         got = gpu_ctx.quantify(model, default_params(cut_off=1e-30))
         assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row)
         assert rel(got.rare_event, want.rare_event) < TOL and rel(got.mcub, want.mcub) < TOL
-        times.append(got.elapsed_kernel_ms)
-    assert times[1] < times[0]  # first call: filter + a refine pass over nearly every row; then WAVE_STREAM
+        ran.append(gpu_ctx.last_kernel_variant())
+    # first call: filter + a refine pass over nearly every row; its candidate count then steers AUTO away
+    assert ran == [_capi.KERNEL_FILTER_REFINE, _capi.KERNEL_WAVE_STREAM, _capi.KERNEL_WAVE_STREAM]
+    # with the default cut-off few rows survive and AUTO stays with filter/refine
+    for _ in range(2):
+        gpu_ctx.quantify(model, default_params())
+    assert gpu_ctx.last_kernel_variant() == _capi.KERNEL_FILTER_REFINE
     model.close()
 
 
