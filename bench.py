@@ -149,23 +149,26 @@ def main():
     else:
         result = canopy_amd.combine_partials([ctx.fetch_partial()])
 
-    auto_fr = (args.kernel == 0 and args.cut_off > 0 and info.n_events <= (1 << 18)
-               and info.n_rows >= (8_000_000 if info.n_events <= 2048 else 1_000_000))
+    variant = ctx.last_kernel_variant()  # what AUTO resolved to, reported by the library
     kernel_label = {1: "k_rows (lane per row, L2 gather)", 2: "k_rows (lane per row, LDS table)",
                     3: "k_ws (wave-slab stream)", 4: "k_vs (value scatter)",
-                    5: "k_fr_filter + k_fr_refine (filter, then exact refine)"}.get(
-        args.kernel, "k_fr_filter + k_fr_refine (filter, then exact refine)" if auto_fr else
-        ("k_ws (wave-slab stream)" if info.n_events > 2048 else "k_rows (lane per row, LDS table)"))
+                    5: "k_fr_filter_q8 + k_fr_refine (quantised conservative filter, then exact refine)"
+                    if info.n_events <= 112 * 1024 else "k_fr_filter + k_fr_refine (filter, then exact refine)"}[variant]
     if rank == 0:
         total_rows = info.n_rows * world
         ms_per_step = elapsed * 1e3 / args.steps
         k_ms = k_ms_sum / max(n_timed, 1)
         achieved = info.algorithmic_bytes / (k_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (benchmarks/pmc.sh): only quoted
+        # when they were collected for the kernel and workload that just ran
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("variant") == variant and tj.get("rows") == info.n_rows and tj.get("n_events") == info.n_events \
+                        and tj.get("cut_off") == args.cut_off:
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -178,7 +181,7 @@ def main():
                 "rows_per_gpu": info.n_rows, "nnz_per_gpu": info.nnz, "n_events": info.n_events,
                 "sharding": "row-sharded, %d rank(s), one all-reduce of %d B" % (world, world * 64) if world > 1
                 else "single GPU, no collective",
-                "seed": SEED, "kernel": args.kernel,
+                "seed": SEED, "kernel": args.kernel, "kernel_ran": variant,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -186,7 +189,9 @@ def main():
                 "kernel": kernel_label,
                 "algorithmic_bytes_per_launch": info.algorithmic_bytes,
                 "bytes_per_cut_set": info.algorithmic_bytes / max(info.n_rows, 1),
-                "stream_bytes_per_launch": info.stream_bytes, "avg_kernel_ms": k_ms, "avg_pass_ms": tot_ms_sum / max(n_timed, 1), "launches_timed": n_timed,
+                "stream_bytes_per_launch": info.stream_bytes,
+                "streamed_gbs": info.stream_bytes / (k_ms * 1e-3) / 1e9 if (info.stream_bytes and variant == 5) else None,
+                "avg_kernel_ms": k_ms, "avg_pass_ms": tot_ms_sum / max(n_timed, 1), "launches_timed": n_timed,
             },
             "result": {"rare_event": result.rare_event, "mcub": result.mcub, "n_kept": result.n_kept,
                        "argmax_row": result.argmax_row},

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
                                                              const uint8_t* __restrict__ q8, int32_t n_events,
                                                              int64_t n_rows, int64_t n_slabs, int threshold,
                                                              uint16_t* __restrict__ cand_list, unsigned* __restrict__ cand_cnt,
-                                                             unsigned long long* __restrict__ cand_count) {
+                                                             unsigned long long* __restrict__ cand_count, int abl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* sums = reinterpret_cast<unsigned*>(smem);
     uint8_t* tab = reinterpret_cast<uint8_t*>(smem + kQ8SumsBytes);
@@ -308,7 +308,10 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t c = cb + (int64_t)(U + u) * kQ8Waves;
-                qn[u] = stream[(c < c1 ? c : total_chunks) * kWave + lane];
+                // timing ablation (CANOPY_FR_DEBUG=1, wrong results): every slab re-reads its first 64 chunks, which
+                // stay cache-resident -> the pass without its HBM stream
+                const int64_t cc = (abl & 1) ? c0 + ((c - c0) & 63) : c;
+                qn[u] = stream[(c < c1 ? cc : total_chunks) * kWave + lane];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -563,6 +566,7 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
         if (e != hipSuccess) return e;
     }
     static const int u = getenv("CANOPY_FR_QU") ? atoi(getenv("CANOPY_FR_QU")) : 2; // tuning only
+    static const int fr_dbg = getenv("CANOPY_FR_DEBUG") ? atoi(getenv("CANOPY_FR_DEBUG")) : 0; // timing ablations only
     const size_t lds = kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16 + (kQ8SlabRows / 64) * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -575,7 +579,7 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
     int64_t grid = n_cu;
     if (grid > n_slabs) grid = n_slabs;
     if (grid < 1) grid = 1;
-#define Q8_GO(UU) hipLaunchKernelGGL(k_fr_filter_q8<UU>, dim3((unsigned)grid), dim3(kQ8Threads), lds, s, reinterpret_cast<const uint4*>(stream), fr_off, total_chunks, q8_buf, n_events, n_rows, n_slabs, threshold, cand_list, cand_cnt, cand_count)
+#define Q8_GO(UU) hipLaunchKernelGGL(k_fr_filter_q8<UU>, dim3((unsigned)grid), dim3(kQ8Threads), lds, s, reinterpret_cast<const uint4*>(stream), fr_off, total_chunks, q8_buf, n_events, n_rows, n_slabs, threshold, cand_list, cand_cnt, cand_count, fr_dbg)
     if (u == 1) Q8_GO(1); else if (u == 4) Q8_GO(4); else Q8_GO(2);
 #undef Q8_GO
     return hipGetLastError();
