@@ -36,6 +36,11 @@ int main(int argc, char** argv) {
         canopy::quant_params prm;
         prm.cut_off = 0.0;
         const canopy_quant_result r = ctx.quantify(model, prm);
+        // uncertainty trials: the same cut sets under three probability vectors in one call (trial 1 = point values)
+        std::vector<double> trials;
+        for (double f : {0.5, 1.0, 2.0})
+            for (double pj : p) trials.push_back(pj * f > 1.0 ? 1.0 : pj * f);
+        const std::vector<canopy_quant_result> rb = ctx.quantify_batch(model, trials, 3, prm);
         // Monte-Carlo through the same tree's gate DAG
         std::vector<int32_t> gt((size_t)info.n_gates), gm((size_t)info.n_gates), ap((size_t)info.n_gates + 1),
             ar((size_t)(info.n_dag_args > 0 ? info.n_dag_args : 1));
@@ -50,9 +55,11 @@ int main(int argc, char** argv) {
         canopy_mc_result mc;
         if (canopy_mc_run(ctx.get(), dag.get(), &mp, &mc) != CANOPY_OK) throw canopy::error(CANOPY_ERR_HIP, "canopy_mc_run", canopy_last_error(ctx.get()));
         std::printf("{\"model\": \"%s\", \"top\": \"%s\", \"basic_events\": %d, \"cut_sets\": %lld, \"rare_event\": %.17g, "
-                    "\"mcub\": %.17g, \"monte_carlo\": %.9g, \"mc_std_error\": %.3g, \"mc_trials\": %lld}\n",
+                    "\"mcub\": %.17g, \"batch_rare_event\": [%.17g, %.17g, %.17g], \"monte_carlo\": %.9g, \"mc_std_error\": %.3g, "
+                    "\"mc_trials\": %lld}\n",
                     path, canopy_ft_gate_name(ft.get(), info.top_gate), info.n_basic_events, (long long)n_sets,
-                    r.rare_event, r.mcub, mc.estimate, mc.std_error, (long long)mc.num_trials);
+                    r.rare_event, r.mcub, rb[0].rare_event, rb[1].rare_event, rb[2].rare_event, mc.estimate, mc.std_error,
+                    (long long)mc.num_trials);
     } catch (const canopy::error& e) {
         std::fprintf(stderr, "canopy: %s\n", e.what());
         return 1;

@@ -77,6 +77,15 @@ public:
         check(canopy_quantify_fetch(get(), &p), "canopy_quantify_fetch");
         return p;
     }
+    // K probability vectors against one model (p_trials: n_trials x n_events, row-major); results[k] is what
+    // quantify() returns after set_probabilities(p_trials[k]). info may be null.
+    std::vector<canopy_quant_result> quantify_batch(const model_ptr& m, const std::vector<double>& p_trials, int32_t n_trials,
+                                                    const canopy_quant_params& params = quant_params(),
+                                                    canopy_batch_info* info = nullptr) const {
+        std::vector<canopy_quant_result> r((size_t)(n_trials > 0 ? n_trials : 0));
+        check(canopy_quantify_batch(get(), m.get(), p_trials.data(), n_trials, &params, 0, r.data(), info), "canopy_quantify_batch");
+        return r;
+    }
     void synchronize() const { check(canopy_ctx_synchronize(get()), "canopy_ctx_synchronize"); }
 
 private:

@@ -203,3 +203,5 @@ def test_cpp_example_runs_end_to_end(canopy_lib, tmp_path):
     assert r["cut_sets"] == 6 and r["basic_events"] == 7 and r["top"] == "TOP"
     assert abs(r["rare_event"] - 0.033) < 1e-15 and abs(r["mcub"] - 0.03260898707329901) < 1e-15
     assert abs(r["monte_carlo"] - 0.0308655046) < 5 * r["mc_std_error"]
+    lo, mid, hi = r["batch_rare_event"]  # trials at 0.5x, 1x, 2x the point probabilities (canopy_quantify_batch)
+    assert mid == r["rare_event"] and lo < mid < hi
