@@ -26,7 +26,7 @@ UPLOAD_VALIDATE = 1
 UPLOAD_DEVICE_POINTERS = 2
 
 APPROX_RARE_EVENT, APPROX_MCUB, APPROX_BOTH = 1, 2, 3
-QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK = 1, 2, 4
+QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK, QUANT_IMPORTANCE = 1, 2, 4, 8
 BATCH_LOG_INPUT = 1
 GATE_AND, GATE_OR, GATE_ATLEAST, GATE_XOR, GATE_NOT, GATE_NAND, GATE_NOR, GATE_NULL = range(8)
 KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER, KERNEL_FILTER_REFINE = range(6)
@@ -112,6 +112,8 @@ SIGNATURES = {
     "canopy_combine_partials": (C.c_int, [C.POINTER(Partial), C.c_int32, C.c_uint32, C.POINTER(QuantResult)]),
     "canopy_fetch_row_logp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "canopy_fetch_keep_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "canopy_fetch_importance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "canopy_ctx_set_importance_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "canopy_quantify_batch_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(QuantParams), C.c_uint32,
                                               C.c_void_p]),
     "canopy_quantify_batch_fetch": (C.c_int, [C.c_void_p, C.POINTER(Partial), C.c_int32, C.POINTER(BatchInfo)]),

@@ -162,6 +162,7 @@ void canopy_ctx_free(canopy_ctx* ctx) {
     if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
     if (ctx->d_row_logp) (void)hipFree(ctx->d_row_logp);
     if (ctx->d_keep_mask) (void)hipFree(ctx->d_keep_mask);
+    if (ctx->d_importance) (void)hipFree(ctx->d_importance);
     if (ctx->d_fr_count) (void)hipFree(ctx->d_fr_count);
     if (ctx->h_fr_count) (void)hipHostFree(ctx->h_fr_count);
     if (ctx->d_fr_list) (void)hipFree(ctx->d_fr_list);
@@ -493,7 +494,16 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     }
 
     const bool want_rows = (params->flags & CANOPY_QUANT_ROW_LOGP) != 0;
-    const bool want_mask = (params->flags & CANOPY_QUANT_KEEP_MASK) != 0;
+    const bool want_imp = (params->flags & CANOPY_QUANT_IMPORTANCE) != 0;
+    const bool want_mask = (params->flags & CANOPY_QUANT_KEEP_MASK) != 0 || want_imp; // importance walks the exact keep mask
+    if (want_imp && ctx->ext_importance && ctx->ext_importance_n != m->n_events)
+        return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "importance buffer was set for another number of basic events");
+    if (want_imp && !ctx->ext_importance && ctx->importance_cap < m->n_events) {
+        if (ctx->d_importance) (void)hipFree(ctx->d_importance);
+        ctx->d_importance = nullptr; ctx->importance_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_importance, sizeof(double) * (size_t)(m->n_events > 0 ? m->n_events : 1)));
+        ctx->importance_cap = m->n_events;
+    }
     if (want_rows && ctx->row_logp_cap < m->n_rows) {
         if (ctx->d_row_logp) (void)hipFree(ctx->d_row_logp);
         ctx->d_row_logp = nullptr; ctx->row_logp_cap = 0;
@@ -601,9 +611,15 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
                                  ctx->gather_rank, variant == CANOPY_KERNEL_FILTER_REFINE ? ctx->d_fr_count : nullptr, ctx->stream));
     ctx->last_variant = variant;
     HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
+    if (want_imp) { // after the timed pass: one walk over the kept rows
+        double* dst = ctx->ext_importance ? ctx->ext_importance : ctx->d_importance;
+        HIP_TRY(ctx, hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(m->n_events > 0 ? m->n_events : 1), ctx->stream));
+        HIP_TRY(ctx, launch_importance(ctx->d_keep_mask, m->n_rows, m->d_row_ptr, m->d_col_idx, m->d_logp, dst, ctx->stream));
+    }
+    ctx->last_has_importance = want_imp;
     if (ev == ctx->ev_last) ctx->last_timed = true;
     ctx->last_has_row_logp = want_rows;
-    ctx->last_has_mask = want_mask;
+    ctx->last_has_mask = (params->flags & CANOPY_QUANT_KEEP_MASK) != 0;
     return CANOPY_OK;
 }
 
@@ -699,6 +715,24 @@ canopy_status canopy_fetch_keep_mask(canopy_ctx* ctx, const canopy_model* m, int
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_keep_mask + first_word, sizeof(uint64_t) * (size_t)n_words, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANOPY_OK;
+}
+
+canopy_status canopy_fetch_importance(canopy_ctx* ctx, const canopy_model* m, double* contrib) {
+    if (!ctx || !m || (!contrib && m->n_events > 0)) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (!ctx->last_has_importance) return fail(ctx, CANOPY_ERR_STATE, "last pass did not request CANOPY_QUANT_IMPORTANCE");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const double* src = ctx->ext_importance ? ctx->ext_importance : ctx->d_importance;
+    if (m->n_events > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(contrib, src, sizeof(double) * (size_t)m->n_events, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANOPY_OK;
+}
+
+canopy_status canopy_ctx_set_importance_buffer(canopy_ctx* ctx, void* device_buffer, int32_t n_events) {
+    if (!ctx || (device_buffer && n_events < 0)) return CANOPY_ERR_INVALID_ARGUMENT;
+    ctx->ext_importance = static_cast<double*>(device_buffer);
+    ctx->ext_importance_n = device_buffer ? n_events : 0;
     return CANOPY_OK;
 }
 

@@ -33,7 +33,11 @@ struct canopy_ctx {
     int64_t row_logp_cap = 0;
     uint64_t* d_keep_mask = nullptr;
     int64_t keep_mask_cap = 0;
-    bool last_has_row_logp = false, last_has_mask = false;
+    bool last_has_row_logp = false, last_has_mask = false, last_has_importance = false;
+    double* d_importance = nullptr;     // [importance_cap] contributions of the last pass that asked for them
+    int64_t importance_cap = 0;
+    double* ext_importance = nullptr;   // caller-owned buffer instead (cross-GPU all-reduce), ext_importance_n doubles
+    int32_t ext_importance_n = 0;
 
     hipEvent_t ev_last[3] = {nullptr, nullptr, nullptr};
     bool last_timed = false;
@@ -134,6 +138,8 @@ hipError_t launch_finalize(const double* block_partials, int n_blocks, double* o
                            int world, int rank, unsigned long long* fr_count, hipStream_t s);
 
 // kernels_build.hip
+hipError_t launch_importance(const uint64_t* keep_mask, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx,
+                             const double* logp, double* contrib, hipStream_t s);
 hipError_t launch_validate_csr(const int64_t* row_ptr, const int32_t* col_idx, int64_t n_rows,
                                int64_t nnz, int32_t n_events, int64_t* d_status /*[2]: first bad row, max len*/,
                                hipStream_t s);

@@ -147,6 +147,37 @@ int grid_for(int64_t n, int block) {
 
 hipError_t scan_inclusive_i64(int64_t* data, int64_t n, hipStream_t s) { return scan_inclusive(data, n, s); }
 
+namespace {
+// Importance contributions: a thread walks the kept rows of one mask word; P_i = exp(s_i) with s_i the same
+// CSR-order sum as the pass itself, added to every event of the row (fp64 global atomics, no fixed order).
+__global__ __launch_bounds__(256) void k_importance(const uint64_t* __restrict__ mask, int64_t n_words, int64_t n_rows,
+                                                    const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                                    const double* __restrict__ logp, double* __restrict__ contrib) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint64_t m = mask[w];
+    const int64_t left = n_rows - w * 64;
+    if (left < 64) m &= (1ULL << left) - 1ULL;
+    for (; m != 0ULL; m &= m - 1) {
+        const int64_t r = w * 64 + __builtin_ctzll(m);
+        const int64_t b = row_ptr[r], e = row_ptr[r + 1];
+        double s = 0.0;
+        for (int64_t k = b; k < e; ++k) s = s + logp[col_idx[k]]; // plain adds, CSR order
+        const double P = exp(s);
+        for (int64_t k = b; k < e; ++k) unsafeAtomicAdd(&contrib[col_idx[k]], P);
+    }
+}
+} // namespace
+
+hipError_t launch_importance(const uint64_t* keep_mask, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx,
+                             const double* logp, double* contrib, hipStream_t s) {
+    const int64_t n_words = (n_rows + 63) / 64;
+    if (n_words == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_importance, dim3(grid_for(n_words, 256)), dim3(256), 0, s, keep_mask, n_words, n_rows, row_ptr,
+                       col_idx, logp, contrib);
+    return hipGetLastError();
+}
+
 hipError_t launch_validate_csr(const int64_t* row_ptr, const int32_t* col_idx, int64_t n_rows, int64_t nnz,
                                int32_t n_events, int64_t* d_status, hipStream_t s) {
     hipLaunchKernelGGL(k_validate, dim3(grid_for(n_rows, 256)), dim3(256), 0, s, row_ptr, col_idx, n_rows, nnz,

@@ -101,6 +101,17 @@ class Context:
         return QuantResult(res.rare_event, res.mcub, res.n_kept, res.argmax_row, res.max_logp,
                            res.elapsed_kernel_ms)
 
+    def fetch_importance(self, model):
+        """contrib[j] = sum of P_i over kept cut sets containing event j (last pass with QUANT_IMPORTANCE)."""
+        out = np.empty(model.info().n_events, dtype=np.float64)
+        capi.check(capi.lib().canopy_fetch_importance(self._h, model.handle, out.ctypes.data), "canopy_fetch_importance",
+                   self._h)
+        return out
+
+    def set_importance_buffer(self, device_ptr, n_events):
+        capi.check(capi.lib().canopy_ctx_set_importance_buffer(self._h, device_ptr, n_events),
+                   "canopy_ctx_set_importance_buffer", self._h)
+
     # -- batched quantification: K probability vectors against one model (N4) ----------------------
     def quantify_batch_async(self, model, p_trials, params=None, log_input=False, device_out=None):
         """p_trials: [n_trials, n_events]. device_out: raw device pointer (int) for the records, or None."""
@@ -265,6 +276,17 @@ def default_params(cut_off=None, limit_order=None, flags=0, kernel=capi.KERNEL_A
     p.flags = flags
     p.kernel = kernel
     return p
+
+
+def importance_measures(contrib, p, rare_event):
+    """Host arithmetic on the contributions: Fussell-Vesely, rare-event Birnbaum, risk reduction worth."""
+    contrib = np.asarray(contrib, dtype=np.float64)
+    p = np.asarray(p, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        fv = contrib / rare_event if rare_event > 0 else np.zeros_like(contrib)
+        birnbaum = np.where(p > 0, contrib / p, 0.0)
+        rrw = np.where(fv < 1, 1.0 / (1.0 - fv), np.inf)
+    return {"fussell_vesely": fv, "birnbaum": birnbaum, "risk_reduction_worth": rrw}
 
 
 def synthetic_probabilities(seed, n_events):

@@ -172,7 +172,9 @@ typedef enum canopy_approximation { /* reference settings.h:19 Approximation */
 enum {
     CANOPY_QUANT_CLAMP = 1u,       /* rare_event = min(1, sum) */
     CANOPY_QUANT_ROW_LOGP = 2u,    /* also write s_i for every row (R*8 B of extra HBM stores) */
-    CANOPY_QUANT_KEEP_MASK = 4u    /* also write the survivor bitmask, bit (i%64) of word i/64 */
+    CANOPY_QUANT_KEEP_MASK = 4u,   /* also write the survivor bitmask, bit (i%64) of word i/64 */
+    CANOPY_QUANT_IMPORTANCE = 8u   /* also accumulate the per-event importance contributions, see
+                                      canopy_fetch_importance (one extra pass over the kept rows) */
 };
 
 typedef struct canopy_quant_params {
@@ -260,6 +262,20 @@ CANOPY_API canopy_status canopy_fetch_row_logp(canopy_ctx* ctx, const canopy_mod
                                                int64_t first_row, int64_t n, double* out);
 CANOPY_API canopy_status canopy_fetch_keep_mask(canopy_ctx* ctx, const canopy_model* model,
                                                 int64_t first_word, int64_t n_words, uint64_t* out);
+
+/*
+ * Importance contributions of the last pass that requested CANOPY_QUANT_IMPORTANCE:
+ *   contrib[j] = sum of P_i over the KEPT cut sets that contain basic event j     (n_events doubles)
+ * from which the usual measures follow on the host: Fussell-Vesely FV_j = contrib[j] / rare_event, rare-event
+ * Birnbaum B_j = contrib[j] / p[j], risk reduction worth 1 / (1 - FV_j). (Importance analysis is a flag of the
+ * reference's Settings, src/mef/openpsa/settings.h:262-279; the reference has no implementation.) The kept set and
+ * every P_i are those of the pass itself; the sums are fp64 atomic adds in no fixed order, so they agree with the
+ * oracle to <= 1e-12 relative but are not bitwise reproducible. Shards add: the cross-GPU combine is one sum
+ * all-reduce of n_events doubles -- canopy_ctx_set_importance_buffer points the pass at a caller-owned device
+ * buffer (e.g. a torch tensor handed to RCCL); NULL returns to the context's own buffer.
+ */
+CANOPY_API canopy_status canopy_fetch_importance(canopy_ctx* ctx, const canopy_model* model, double* contrib);
+CANOPY_API canopy_status canopy_ctx_set_importance_buffer(canopy_ctx* ctx, void* device_buffer, int32_t n_events);
 
 /*
  * Device time of the last `canopy_quantify_async` row kernel alone, measured with HIP events

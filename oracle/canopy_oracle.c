@@ -277,6 +277,30 @@ int oracle_quantify_product_domain(int64_t n_rows, const int64_t* row_ptr, const
     return 0;
 }
 
+int oracle_importance(int64_t n_rows, int32_t n_events, const int64_t* row_ptr, const int32_t* col_idx,
+                      const double* p, double cut_off, int32_t limit_order, double* contrib) {
+    if (n_rows < 0 || n_events < 0 || !row_ptr || !contrib || limit_order < 0) return -1;
+    double* logp = (double*)malloc(sizeof(double) * (size_t)(n_events > 0 ? n_events : 1));
+    long double* acc = (long double*)calloc((size_t)(n_events > 0 ? n_events : 1), sizeof(long double));
+    if (!logp || !acc) { free(logp); free(acc); return -1; }
+    for (int32_t jx = 0; jx < n_events; ++jx) {
+        if (!(p[jx] >= 0.0 && p[jx] <= 1.0)) { free(logp); free(acc); return -1; }
+        logp[jx] = log(p[jx]);
+    }
+    const double log_cut = cut_off > 0.0 ? log(cut_off) : -INFINITY;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        double s = 0.0;
+        for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) s = s + logp[col_idx[k]]; /* CSR order */
+        const int64_t len = row_ptr[i + 1] - row_ptr[i];
+        if (!(s >= log_cut) || (limit_order != 0 && len > limit_order)) continue;
+        const long double P = (long double)exp(s);
+        for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) acc[col_idx[k]] += P;
+    }
+    for (int32_t jx = 0; jx < n_events; ++jx) contrib[jx] = (double)acc[jx];
+    free(logp); free(acc);
+    return 0;
+}
+
 /* ---- K6: Monte-Carlo through the gate DAG ------------------------------------------------------- */
 
 typedef struct mc_job {

@@ -70,13 +70,23 @@ void oracle_synth_probabilities(uint64_t seed, int32_t n_events, double* p);
 
 /*
  * K6 restatement: direct Monte-Carlo through the gate DAG (include/canopy.h, canopy_dag_view). Same
- * counter-based draw as the device: sample n of event j is TRUE iff
- * (mix64(mix64(key ^ j) + n) >> 11) < ceil(p_j * 2^53), key = stream key of (seed, stream 4).
- * Gates in the caller's (topological) order, one u64 word of 64 samples per node. Returns hits, or -1.
+ * counter-based draw as the device: sample l of 64-sample word w of event j owns a 53-bit uniform u whose
+ * bit (52 - k) is bit l of mix64(mix64(key ^ j) + 64 w + k); TRUE iff u < ceil(p_j * 2^53); key = stream key
+ * of (seed, stream 4). Evaluated per sample, most significant bit first (the device resolves 64 samples at a
+ * time with bit masks). Gates in the caller's (topological) order, one u64 word of 64 samples per node.
+ * Returns hits, or -1.
  */
 int64_t oracle_mc(int32_t n_events, int32_t n_gates, const int32_t* gate_type, const int32_t* gate_min,
                   const int32_t* arg_ptr, const int32_t* args, int32_t top, const double* p, uint64_t seed,
                   int64_t first_sample, int64_t num_trials, int32_t n_threads);
+
+/*
+ * Importance contributions (N4): contrib[j] = sum of P_i = exp(s_i) over the KEPT cut sets that contain basic
+ * event j (same s_i, same filter as oracle_quantify). Fussell-Vesely importance is contrib[j] / rare_event,
+ * the rare-event Birnbaum importance contrib[j] / p[j]. Accumulated in long double. Returns 0 or -1.
+ */
+int oracle_importance(int64_t n_rows, int32_t n_events, const int64_t* row_ptr, const int32_t* col_idx,
+                      const double* p, double cut_off, int32_t limit_order, double* contrib);
 
 /* nnz-balanced contiguous shard bounds (mirror of canopy_shard_rows). */
 void oracle_shard_rows(const int64_t* row_ptr, int64_t n_rows, int32_t n_shards, int64_t* bounds);

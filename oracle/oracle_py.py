@@ -55,6 +55,8 @@ def lib():
         l.oracle_mc.restype = C.c_int64
         l.oracle_mc.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                 C.c_uint64, C.c_int64, C.c_int64, C.c_int32]
+        l.oracle_importance.restype = C.c_int
+        l.oracle_importance.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p]
         _lib = l
     return _lib
 
@@ -83,6 +85,19 @@ def quantify(row_ptr, col_idx, p, cut_off=1e-8, limit_order=20, n_threads=1, row
     if rc != 0:
         raise ValueError("oracle_quantify: invalid input")
     return Quant(res, row_logp, mask)
+
+
+def importance(row_ptr, col_idx, p, cut_off=1e-8, limit_order=20):
+    """contrib[j] = sum of P_i over kept cut sets containing event j (oracle_importance)."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    out = np.zeros(len(p), dtype=np.float64)
+    rc = lib().oracle_importance(len(row_ptr) - 1, len(p), row_ptr.ctypes.data, col_idx.ctypes.data, p.ctypes.data,
+                                 cut_off, limit_order, out.ctypes.data)
+    if rc != 0:
+        raise ValueError("oracle_importance: invalid input")
+    return out
 
 
 def product_domain(row_ptr, col_idx, p):
