@@ -24,6 +24,8 @@ def oracle():
 @pytest.fixture(scope="session")
 def canopy_lib():
     """The product library. Built on demand with hipcc (cross-compiles gfx950 without a GPU)."""
+    import torch  # noqa: F401  before libcanopy.so: the process then maps ONE HIP/HSA runtime (torch's copies carry the
+    #               same SONAMEs as /opt/rocm's), whichever of the two libraries touches the GPU first
     from canopy_amd import build
     build.build()
     from canopy_amd import _capi
