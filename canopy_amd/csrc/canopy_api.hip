@@ -371,10 +371,12 @@ int auto_variant(const canopy_model* m) {
 canopy_status build_fr(canopy_ctx* ctx, canopy_model* m) {
     if (m->fr_state != 0) return CANOPY_OK;
     bool ok = false;
-    HIP_TRY(ctx, fr_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, m->max_row_len, &m->d_fr_stream,
-                          &m->d_fr_off, &m->fr_total_chunks, &m->n_fr_slabs, &ok, ctx->stream));
-    m->fr_state = ok ? 1 : -1;
-    if (ok) m->device_bytes += (m->fr_total_chunks + 1) * 1024 + (m->n_fr_slabs + 1) * 8;
+    HIP_TRY(ctx, fr_offsets(m->d_row_ptr, m->n_rows, m->n_events, &m->d_fr_off, &m->fr_total_chunks, &m->n_fr_slabs, &ok, ctx->stream));
+    if (!ok) { m->fr_state = -1; return CANOPY_OK; }
+    HIP_TRY(ctx, fr_build_sorted32(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, m->d_fr_off, m->fr_total_chunks,
+                                   m->n_fr_slabs, &m->d_fr_stream, ctx->stream));
+    m->device_bytes += (m->fr_total_chunks + 1) * 1024 + (m->n_fr_slabs + 1) * 8;
+    m->fr_state = 1;
     return CANOPY_OK;
 }
 

@@ -66,49 +66,63 @@ int fr_slab_rows_for(int32_t n_events) {
     return n_events <= (1 << 17) ? 16384 : 8192;
 }
 
-// ---- builder: one thread per slab, greedy placement of the slab's entries into 64-entry groups by
-// column (target group = the column's share of the slab's group count, spill forward when full)
-template <bool WRITE>
-__global__ __launch_bounds__(64) void k_fr_build(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
-                                                 int64_t n_rows, int32_t n_events, int slab_rows, int row_bits,
-                                                 int64_t n_slabs, int gcap,
-                                                 uint8_t* cnt_scratch, int64_t* chunks, const int64_t* __restrict__ fr_off,
-                                                 uint32_t* stream, int* overflow) {
+// ---- builder: one workgroup per slab, counting sort of the slab's entries by column bucket -------------------
+// The filters add in any order, so the stream needs no group structure: a slab's entries are bucket-sorted by
+// column (<= 512 buckets over [0, E)) and cut into 256-entry chunks; only the slab's last chunk is padded
+// (col 0 -> the sink row). Chunks are therefore narrow in column (what the 24-bit repacking and the gathered
+// fp64 filter both want), the stream is as dense as it can be, and the build is parallel.
+constexpr int kFrBuckets = 512;
+
+__global__ __launch_bounds__(256) void k_fr_count_chunks(const int64_t* __restrict__ row_ptr, int64_t n_rows, int slab_rows,
+                                                         int64_t n_slabs, int64_t* __restrict__ chunks) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slabs) return;
     const int64_t r0 = s * slab_rows;
     const int64_t r1 = r0 + slab_rows < n_rows ? r0 + slab_rows : n_rows;
-    const int64_t nnz = row_ptr[r1] - row_ptr[r0];
-    int64_t ng_nom = (nnz + 63) / 64;
-    if (ng_nom < 1) ng_nom = 1;
-    uint8_t* cnt = cnt_scratch + (size_t)s * gcap;
-    for (int g = 0; g < gcap; ++g) cnt[g] = 0;
-    int g_max = -1;
-    const int64_t base = WRITE ? fr_off[s] * kFrChunk : 0;
-    bool ovf = false;
-    for (int64_t r = r0; r < r1 && !ovf; ++r) {
-        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
-            const uint32_t c = (uint32_t)col_idx[k];
-            int g = (int)(((uint64_t)c * (uint64_t)ng_nom) / (uint64_t)n_events);
-            while (g < gcap && cnt[g] >= 64) ++g;
-            if (g >= gcap) { ovf = true; break; }
-            const int slot = cnt[g]++;
-            if (WRITE) stream[base + (int64_t)(g >> 2) * kFrChunk + slot * 4 + (g & 3)] = (c << row_bits) | (uint32_t)(r - r0);
-            g_max = g > g_max ? g : g_max;
-        }
-    }
-    if (ovf) atomicExch(overflow, 1);
-    if (!WRITE) chunks[s] = (int64_t)((g_max + 1 + 3) / 4);
+    chunks[s] = (row_ptr[r1] - row_ptr[r0] + kFrChunk - 1) / kFrChunk;
 }
 
-// largest number of entries any slab holds (sizes the builder's group counters)
-__global__ __launch_bounds__(256) void k_fr_max_nnz(const int64_t* __restrict__ row_ptr, int64_t n_rows, int slab_rows,
-                                                    int64_t n_slabs, unsigned long long* out) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_slabs) return;
+__global__ __launch_bounds__(256) void k_fr_build_sorted(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                                         int64_t n_rows, int32_t n_events, int slab_rows, int row_bits,
+                                                         const int64_t* __restrict__ fr_off, uint32_t* __restrict__ stream) {
+    __shared__ unsigned hist[kFrBuckets + 1];
+    const int64_t s = blockIdx.x;
     const int64_t r0 = s * slab_rows;
     const int64_t r1 = r0 + slab_rows < n_rows ? r0 + slab_rows : n_rows;
-    atomicMax(out, (unsigned long long)(row_ptr[r1] - row_ptr[r0]));
+    const int tid = threadIdx.x;
+    for (int i = tid; i <= kFrBuckets; i += 256) hist[i] = 0u;
+    __syncthreads();
+    const uint64_t nb = (uint64_t)kFrBuckets, ne = (uint64_t)n_events;
+    for (int64_t r = r0 + tid; r < r1; r += 256)
+        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k)
+            atomicAdd(&hist[(unsigned)(((uint64_t)(uint32_t)col_idx[k] * nb) / ne) + 1u], 1u);
+    __syncthreads();
+    if (tid < kWave) { // inclusive scan of the 512 counts (8 per lane) -> hist[b] = first slot of bucket b
+        unsigned loc[8], tot = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { loc[i] = hist[1 + tid * 8 + i]; tot += loc[i]; }
+        unsigned incl = tot;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d, kWave);
+            if (tid >= d) incl += o;
+        }
+        unsigned run = incl - tot;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const unsigned c = loc[i]; hist[1 + tid * 8 + i] = run; run += c; }
+    }
+    __syncthreads();
+    // hist[1 + b] is now the cursor of bucket b
+    uint32_t* out = stream + fr_off[s] * kFrChunk;
+    for (int64_t r = r0 + tid; r < r1; r += 256)
+        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
+            const uint32_t c = (uint32_t)col_idx[k];
+            const unsigned pos = atomicAdd(&hist[(unsigned)(((uint64_t)c * nb) / ne) + 1u], 1u);
+            out[pos] = (c << row_bits) | (uint32_t)(r - r0);
+        }
+    const int64_t nnz = row_ptr[r1] - row_ptr[r0];
+    const int64_t padded = (nnz + kFrChunk - 1) / kFrChunk * kFrChunk;
+    for (int64_t i = nnz + tid; i < padded; i += 256) out[i] = (uint32_t)slab_rows; // col 0 -> the sink row
 }
 
 __global__ __launch_bounds__(256) void k_fr_fill(uint32_t* p, int64_t n, uint32_t v) {
@@ -322,6 +336,14 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     __hip_atomic_fetch_add(&sums[e[k] & kQ8RowMask], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (abl & 2) { // timing ablation (CANOPY_FR_DEBUG=2, wrong results): the LDS work of every chunk twice
+                    unsigned v2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v2[k] = tab[(e[k] >> kQ8RowBits) ^ 1u];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        __hip_atomic_fetch_add(&sums[(e[k] & kQ8RowMask) ^ 1u], v2[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) q[u] = qn[u];
@@ -425,87 +447,51 @@ bool fr_filter_is_quantised(int32_t n_events) { return fr_use_q8(n_events) && fr
 int fr_refine_grid(int n_cu) { return n_cu * 8; }
 int fr_slab_rows(int32_t n_events) { return fr_slab_rows_for(n_events); }
 
-hipError_t fr_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events,
-                    int32_t max_row_len, uint32_t** d_stream_out, int64_t** d_fr_off_out, int64_t* total_chunks_out,
-                    int64_t* n_slabs_out, bool* ok, hipStream_t s) {
+// Chunk offsets of the slabs (ceil(nnz_slab / 256) chunks each), shared by both stream forms.
+hipError_t fr_offsets(const int64_t* d_row_ptr, int64_t n_rows, int32_t n_events, int64_t** d_fr_off_out,
+                      int64_t* total_chunks_out, int64_t* n_slabs_out, bool* ok, hipStream_t s) {
     *ok = false;
     if (n_events > fr_max_events() || n_events < 1) return hipSuccess;
-    const int slab_rows = fr_slab_rows_for(n_events), row_bits = slab_rows > 8192 ? 15 : 14;
+    const int slab_rows = fr_slab_rows_for(n_events);
     const int64_t n_slabs = (n_rows + slab_rows - 1) / slab_rows;
     *n_slabs_out = n_slabs;
-    (void)max_row_len;
-    int64_t max_nnz = 0;
-    if (n_slabs > 0) {
-        unsigned long long* d_max = nullptr;
-        hipError_t e0 = hipMalloc(&d_max, sizeof(unsigned long long));
-        if (e0 != hipSuccess) return e0;
-        e0 = hipMemsetAsync(d_max, 0, sizeof(unsigned long long), s);
-        if (e0 == hipSuccess) {
-            hipLaunchKernelGGL(k_fr_max_nnz, dim3(grid_for(n_slabs, 256)), dim3(256), 0, s, d_row_ptr, n_rows, slab_rows,
-                               n_slabs, d_max);
-            e0 = hipGetLastError();
-        }
-        unsigned long long h_max = 0;
-        if (e0 == hipSuccess) e0 = hipMemcpyAsync(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost, s);
-        if (e0 == hipSuccess) e0 = hipStreamSynchronize(s);
-        (void)hipFree(d_max);
-        if (e0 != hipSuccess) return e0;
-        max_nnz = (int64_t)h_max;
-    }
-    int64_t gcap64 = (max_nnz + 63) / 64;
-    gcap64 = gcap64 + gcap64 / 4 + 32;
-    if (gcap64 > (1 << 22)) return hipSuccess;
-    const int gcap = (int)gcap64;
     int64_t* d_off = nullptr;
-    uint8_t* d_cnt = nullptr;
-    int* d_ovf = nullptr;
-    uint32_t* d_stream = nullptr;
-    auto bail = [&](hipError_t err) {
-        if (d_off) (void)hipFree(d_off);
-        if (d_cnt) (void)hipFree(d_cnt);
-        if (d_ovf) (void)hipFree(d_ovf);
-        if (d_stream) (void)hipFree(d_stream);
-        return err;
-    };
     hipError_t e = hipMalloc(&d_off, sizeof(int64_t) * (size_t)(n_slabs + 1));
-    if (e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)(n_slabs > 0 ? n_slabs : 1) * gcap);
-    if (e == hipSuccess) e = hipMalloc(&d_ovf, sizeof(int));
-    if (e != hipSuccess) return bail(e);
-    e = hipMemsetAsync(d_ovf, 0, sizeof(int), s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_off, 0, sizeof(int64_t), s);
-    if (e != hipSuccess) return bail(e);
-    int ovf = 0;
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d_off, 0, sizeof(int64_t), s);
     int64_t total = 0;
-    if (n_slabs > 0) {
-        hipLaunchKernelGGL((k_fr_build<false>), dim3(grid_for(n_slabs, 64)), dim3(64), 0, s, d_row_ptr, d_col_idx, n_rows,
-                           n_events, slab_rows, row_bits, n_slabs, gcap, d_cnt, d_off + 1, (const int64_t*)nullptr, (uint32_t*)nullptr, d_ovf);
+    if (e == hipSuccess && n_slabs > 0) {
+        hipLaunchKernelGGL(k_fr_count_chunks, dim3(grid_for(n_slabs, 256)), dim3(256), 0, s, d_row_ptr, n_rows, slab_rows, n_slabs,
+                           d_off + 1);
         e = hipGetLastError();
         if (e == hipSuccess) e = scan_inclusive_i64(d_off + 1, n_slabs, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(&ovf, d_ovf, sizeof(int), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipMemcpyAsync(&total, d_off + n_slabs, sizeof(int64_t), hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return bail(e);
-    if (ovf) { (void)bail(hipSuccess); return hipSuccess; }
-    const int64_t n_entries = (total + 1) * kFrChunk;
-    e = hipMalloc(&d_stream, sizeof(uint32_t) * (size_t)n_entries);
-    if (e != hipSuccess) return bail(e);
-    int fg = grid_for(n_entries, 256);
-    if (fg > 4096) fg = 4096;
-    hipLaunchKernelGGL(k_fr_fill, dim3(fg), dim3(256), 0, s, d_stream, n_entries, (uint32_t)slab_rows); // col 0 -> sink
-    if (n_slabs > 0) {
-        hipLaunchKernelGGL((k_fr_build<true>), dim3(grid_for(n_slabs, 64)), dim3(64), 0, s, d_row_ptr, d_col_idx, n_rows,
-                           n_events, slab_rows, row_bits, n_slabs, gcap, d_cnt, (int64_t*)nullptr, (const int64_t*)d_off, d_stream, d_ovf);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return bail(e);
-    (void)hipFree(d_cnt);
-    (void)hipFree(d_ovf);
-    *d_stream_out = d_stream;
+    if (e != hipSuccess) { (void)hipFree(d_off); return e; }
     *d_fr_off_out = d_off;
     *total_chunks_out = total;
     *ok = true;
+    return hipSuccess;
+}
+
+// The column-bucket-sorted 32-bit stream both filters read.
+hipError_t fr_build_sorted32(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events,
+                             const int64_t* d_fr_off, int64_t total_chunks, int64_t n_slabs, uint32_t** d_stream_out,
+                             hipStream_t s) {
+    const int slab_rows = fr_slab_rows_for(n_events), row_bits = slab_rows > 8192 ? 15 : 14;
+    uint32_t* d_stream = nullptr;
+    hipError_t e = hipMalloc(&d_stream, sizeof(uint32_t) * (size_t)((total_chunks + 1) * kFrChunk));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fr_fill, dim3(1), dim3(256), 0, s, d_stream + total_chunks * kFrChunk, (int64_t)kFrChunk, (uint32_t)slab_rows); // the no-op chunk
+    if (n_slabs > 0) {
+        hipLaunchKernelGGL(k_fr_build_sorted, dim3((unsigned)n_slabs), dim3(256), 0, s, d_row_ptr, d_col_idx, n_rows, n_events,
+                           slab_rows, row_bits, d_fr_off, d_stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(d_stream); return e; }
+    *d_stream_out = d_stream;
     return hipSuccess;
 }
 
