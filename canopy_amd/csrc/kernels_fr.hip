@@ -6,10 +6,12 @@
 // on the survivors only. So:
 //
 //   pass A  k_fr_filter: an UNCONSTRAINED fast pass over all entries whose only job is to find the rows
-//           that might survive. A workgroup (8 waves; two workgroups per CU) owns a slab of 8192
-//           consecutive rows whose running sums live in LDS; the slab's entries arrive as a
-//           column-ordered stream of packed u32 (col << 14 | row_local) built once at prepare time, any
-//           wave takes any chunk: 64 gathers of neighbouring columns, then 64 unordered ds_add_f64.
+//           that might survive. A workgroup owns a slab of 8192 (or 16384) consecutive rows whose running
+//           sums live in LDS; the slab's entries arrive as a column-bucket-sorted stream of packed u32
+//           (col << 14 | row_local) built once at prepare time (k_fr_build_sorted), any wave takes any
+//           chunk: 64 gathers of neighbouring columns, then 64 unordered ds_add_f64. (k_fr_filter_q8, the
+//           form AUTO runs for E <= 112 K, replaces the gathers by byte reads of a conservative 8-bit table
+//           in LDS and the fp64 sums by u32 sums: see there.)
 //           The order of additions is NOT the CSR order here, so s~_i differs from s_i by rounding only
 //           (<= len * 2^-53 * sum|logp|, about 1e-13). Rows with s~_i >= log(cut_off) - delta
 //           (delta = 1e-9 >> that error) go into the slab's candidate list (u16 local row ids, ascending,
