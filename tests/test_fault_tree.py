@@ -205,3 +205,25 @@ def test_cpp_example_runs_end_to_end(canopy_lib, tmp_path):
     assert abs(r["monte_carlo"] - 0.0308655046) < 5 * r["mc_std_error"]
     lo, mid, hi = r["batch_rare_event"]  # trials at 0.5x, 1x, 2x the point probabilities (canopy_quantify_batch)
     assert mid == r["rare_event"] and lo < mid < hi
+
+
+@pytest.mark.gpu
+def test_cpp_benchmark_driver_matches_the_python_path(canopy_lib, gpu_ctx, tmp_path):
+    """benchmarks/bench_quantify.cpp (the native driver over canopy-cpp.h) on a 2e6-row model: same integers and
+    sums as the Python path through the same ABI."""
+    import json
+    import subprocess
+    import canopy_amd
+    exe = tmp_path / "bench_quantify"
+    lib_dir = os.path.join(ROOT, "canopy_amd")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "benchmarks", "bench_quantify.cpp"), "-L", lib_dir, "-lcanopy",
+                    "-Wl,-rpath," + lib_dir, "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe), "2000000", "100000", "6", "3", "1"], check=True, capture_output=True, text=True).stdout
+    r = json.loads(out)
+    model = gpu_ctx.synthetic(20250704, 2_000_000, 100_000, 6)
+    model.set_probabilities(canopy_amd.synthetic_probabilities(20250704, 100_000))
+    want = gpu_ctx.quantify(model)
+    model.close()
+    assert (r["n_kept"], r["argmax_row"], r["rare_event"], r["mcub"]) == (want.n_kept, want.argmax_row, want.rare_event, want.mcub)
+    assert r["kernel_ran"] == 5 and r["value"] > 0 and 0 < r["roofline"]["frac"] < 2
