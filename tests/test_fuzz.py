@@ -1,0 +1,99 @@
+"""Seeded fuzz: random model shapes through every kernel variant, the batch path and the importance pass, against
+the oracle. Shapes the fixed tests do not hit: 1..3 basic events, single rows, empty rows in runs, row counts just
+around the slab / wave-slab sizes, probabilities exactly 0 and 1, cut-offs from 0 to 1, small limit orders."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def random_model(rng):
+    n_events = int(rng.choice([1, 2, 3, 7, 64, 65, 1000, 2049, 5000, 20000]))
+    n_rows = int(rng.choice([1, 2, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 16385, 30011]))
+    max_len = int(min(n_events, rng.choice([1, 2, 4, 10, 25])))
+    lens = rng.integers(0 if rng.random() < 0.3 else 1, max_len + 1, size=n_rows)
+    if rng.random() < 0.3:  # a run of empty rows
+        a = int(rng.integers(0, n_rows))
+        lens[a:a + int(rng.integers(1, 200))] = 0
+    row_ptr = np.zeros(n_rows + 1, dtype=np.int64)
+    row_ptr[1:] = np.cumsum(lens)
+    col = np.empty(int(row_ptr[-1]), dtype=np.int32)
+    for i in range(n_rows):
+        if lens[i]:
+            col[row_ptr[i]:row_ptr[i + 1]] = np.sort(rng.choice(n_events, size=int(lens[i]), replace=False))
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        p = 10.0 ** rng.uniform(-8, 0, size=n_events)
+    elif kind == 1:
+        p = rng.uniform(0.0, 1.0, size=n_events)
+    else:
+        p = 10.0 ** rng.uniform(-4, -1, size=n_events)
+    if rng.random() < 0.4 and n_events > 2:
+        p[rng.integers(0, n_events)] = 1.0
+        p[rng.integers(0, n_events)] = 0.0
+    cut_off = float(rng.choice([0.0, 1e-300, 1e-12, 1e-8, 1e-3, 0.5, 1.0]))
+    limit_order = int(rng.choice([0, 1, 3, 20]))
+    return n_events, row_ptr, col, p, cut_off, limit_order
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def agree(got, want):
+    assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row)
+    if int(want.n_kept):
+        assert got.max_logp == want.max_logp
+    for g, w in ((got.rare_event, want.rare_event), (got.mcub, want.mcub)):
+        if math.isfinite(w) and w > 0:
+            assert rel(g, w) < TOL, (g, w)
+        else:
+            assert g == w or (math.isnan(g) and math.isnan(w)), (g, w)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CANOPY_FUZZ_SEEDS", "24"))))
+def test_random_models_every_variant(gpu_ctx, oracle, seed):
+    from canopy_amd import _capi, default_params
+    rng = np.random.default_rng(1000 + seed)
+    n_events, row_ptr, col, p, cut_off, limit_order = random_model(rng)
+    n_rows = len(row_ptr) - 1
+    want = oracle.quantify(row_ptr, col, p, cut_off=cut_off, limit_order=limit_order, n_threads=2, row_offset=5)
+    model = gpu_ctx.upload(row_ptr, col, n_events, row_offset=5)
+    model.set_probabilities(p)
+    max_len = int(np.diff(row_ptr).max())
+    kernels = [_capi.KERNEL_AUTO, _capi.KERNEL_ROWS, _capi.KERNEL_WAVE_STREAM]
+    if n_events <= 12288:
+        kernels.append(_capi.KERNEL_ROWS_LDS)
+    if max_len <= 4095:
+        kernels.append(_capi.KERNEL_VALUE_SCATTER)
+    for kern in kernels:
+        got = gpu_ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order, kernel=kern,
+                                                     flags=_capi.QUANT_ROW_LOGP | _capi.QUANT_KEEP_MASK))
+        agree(got, want)
+        assert np.array_equal(gpu_ctx.fetch_row_logp(model), want.row_logp), kern
+        assert np.array_equal(gpu_ctx.fetch_keep_mask(model), want.keep_mask), kern
+    if cut_off > 0:
+        got = gpu_ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order, kernel=_capi.KERNEL_FILTER_REFINE,
+                                                     flags=_capi.QUANT_KEEP_MASK))
+        agree(got, want)
+        assert np.array_equal(gpu_ctx.fetch_keep_mask(model), want.keep_mask)
+    # importance contributions behind AUTO
+    gpu_ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order, flags=_capi.QUANT_IMPORTANCE))
+    contrib = gpu_ctx.fetch_importance(model)
+    ref = oracle.importance(row_ptr, col, p, cut_off=cut_off, limit_order=limit_order)
+    assert np.array_equal(contrib == 0, ref == 0)
+    nz = (ref != 0) & np.isfinite(ref)
+    if nz.any():
+        assert np.max(np.abs(contrib[nz] - ref[nz]) / ref[nz]) < TOL
+    # batch: three perturbed vectors
+    pt = np.clip(p[None, :] * np.exp(0.5 * rng.standard_normal((3, n_events))), 0.0, 1.0)
+    res, _ = gpu_ctx.quantify_batch(model, pt, default_params(cut_off=cut_off, limit_order=limit_order))
+    for k in range(3):
+        agree(res[k], oracle.quantify(row_ptr, col, pt[k], cut_off=cut_off, limit_order=limit_order, row_offset=5,
+                                      want_rows=False))
+    model.close()
+    assert n_rows >= 1
