@@ -307,8 +307,9 @@ canopy_status canopy_dag_upload(canopy_ctx* ctx, const canopy_dag_view* v, canop
         if (((type == CANOPY_GATE_NOT || type == CANOPY_GATE_NULL) && n_args != 1) || n_args < 1)
             return fail(ctx, CANOPY_ERR_INVALID_MODEL, "gate " + std::to_string(g) + ": wrong number of arguments");
         if (type == CANOPY_GATE_ATLEAST) {
-            if (!v->gate_min || n_args > kMaxAtleastArgs || v->gate_min[g] < 0 || v->gate_min[g] > 63)
-                return fail(ctx, CANOPY_ERR_UNSUPPORTED, "ATLEAST gate " + std::to_string(g) + ": need 0 <= K <= 63 and <= 63 arguments");
+            // K above the argument count is legal (the gate is then constantly FALSE); the descriptor keeps 8 bits of K
+            if (!v->gate_min || n_args > kMaxAtleastArgs || v->gate_min[g] < 0 || v->gate_min[g] > 255)
+                return fail(ctx, CANOPY_ERR_UNSUPPORTED, "ATLEAST gate " + std::to_string(g) + ": need 0 <= K <= 255 and <= 63 arguments");
         }
         for (int32_t k = b; k < e; ++k) {
             const int32_t raw = v->args[k];

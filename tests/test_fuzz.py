@@ -97,3 +97,50 @@ def test_random_models_every_variant(gpu_ctx, oracle, seed):
                                       want_rows=False))
     model.close()
     assert n_rows >= 1
+
+
+def random_dag(rng):
+    from canopy_amd import _capi as c
+    n_events = int(rng.choice([1, 2, 5, 17, 64, 80]))
+    n_gates = int(rng.choice([0, 1, 3, 20, 120, 300]))
+    gate_type, gate_min, arg_ptr, args = [], [], [0], []
+    for g in range(n_gates):
+        n_prev = n_events + g
+        t = int(rng.choice([c.GATE_AND, c.GATE_OR, c.GATE_ATLEAST, c.GATE_XOR, c.GATE_NOT, c.GATE_NAND, c.GATE_NOR, c.GATE_NULL]))
+        if t in (c.GATE_NOT, c.GATE_NULL):
+            k = 1
+        elif t == c.GATE_ATLEAST:
+            k = int(min(n_prev, rng.choice([2, 3, 7, 8, 30, 63])))
+        else:
+            k = int(min(n_prev, rng.choice([1, 2, 4, 8, 9, 17, 40, 70])))
+        # bias towards recent nodes so that deep chains appear, but keep events reachable
+        pool = np.arange(n_prev)
+        w = np.where(pool >= n_prev - 10, 8.0, 1.0)
+        a = rng.choice(pool, size=k, replace=False, p=w / w.sum())
+        neg = rng.random(k) < 0.2
+        gate_type.append(t)
+        gate_min.append(int(rng.integers(0, k + 2)) if t == c.GATE_ATLEAST else 0)
+        args.extend(int(~x) if n else int(x) for x, n in zip(a, neg))
+        arg_ptr.append(len(args))
+    top = int(rng.integers(0, n_events + n_gates)) if rng.random() < 0.3 else n_events + n_gates - 1
+    dag = dict(n_events=n_events, gate_type=np.array(gate_type, dtype=np.int32), gate_min=np.array(gate_min, dtype=np.int32),
+               arg_ptr=np.array(arg_ptr, dtype=np.int32), args=np.array(args, dtype=np.int32), top=top)
+    p = rng.uniform(0.0, 1.0, n_events) if rng.random() < 0.5 else 10.0 ** rng.uniform(-4, -0.5, n_events)
+    if n_events > 2 and rng.random() < 0.4:
+        p[0], p[1] = 1.0, 0.0
+    return dag, p
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CANOPY_FUZZ_SEEDS", "24"))))
+def test_random_dags_monte_carlo_bit_exact(gpu_ctx, oracle, seed):
+    from canopy_amd.quantifier import Dag
+    rng = np.random.default_rng(5000 + seed)
+    dag, p = random_dag(rng)
+    d = Dag(gpu_ctx, dag)
+    d.set_probabilities(p)
+    for n, first in ((int(rng.integers(1, 200)), 0), (64 * int(rng.integers(1, 40)) + int(rng.integers(0, 64)), 64 * int(rng.integers(0, 1000))),
+                     (40_000, 128)):
+        got = d.run(seed, n, first_sample=first)
+        want = oracle.mc(dag, p, seed, n, first_sample=first, n_threads=2)
+        assert got.hits == want, (n, first, got.hits, want)
+    d.close()
