@@ -358,15 +358,24 @@ std::vector<CutSet> cut_sets_of(const canopy_ft& ft, int limit_order) {
             throw std::invalid_argument("the tree is not coherent (negation / xor): cut sets are not defined, use the Monte-Carlo DAG");
     for (int x : ft.d_args) if (x < 0) throw std::invalid_argument("the tree has complemented arguments: use the Monte-Carlo DAG");
     std::set<CutSet> done;
+    std::set<CutSet> seen; // partial sets already queued: shared sub-gates reach the same set along many paths
     std::vector<CutSet> work(1, CutSet(1, ft.d_top));
+    seen.insert(work[0]);
     size_t guard = 0;
+    // a partial set that already contains a finished cut set can only yield supersets of it: prune
+    auto dominated = [&](const CutSet& n) {
+        if (done.size() > 4096) return false; // keep the check cheap on big outputs
+        for (const CutSet& m : done)
+            if (m.size() <= n.size() && std::includes(n.begin(), n.end(), m.begin(), m.end())) return true;
+        return false;
+    };
     while (!work.empty()) {
         if (++guard > 4000000 || done.size() > 2000000) throw std::length_error("cut-set expansion exceeds the small-tree budget");
         CutSet cs = work.back();
         work.pop_back();
         size_t gi = cs.size();
         for (size_t i = 0; i < cs.size(); ++i) if (cs[i] >= E) { gi = i; break; }
-        if (gi == cs.size()) { done.insert(cs); continue; }
+        if (gi == cs.size()) { if (!dominated(cs)) done.insert(cs); continue; }
         const int g = cs[gi] - E;
         cs.erase(cs.begin() + (long)gi);
         std::vector<int> a(ft.d_args.begin() + ft.d_ptr[(size_t)g], ft.d_args.begin() + ft.d_ptr[(size_t)g + 1]);
@@ -383,6 +392,7 @@ std::vector<CutSet> cut_sets_of(const canopy_ft& ft, int limit_order) {
             int n_events = 0;
             for (int x : n) n_events += (x < E);
             if (limit_order > 0 && n_events > limit_order) continue; // only grows from here
+            if (!seen.insert(n).second || dominated(n)) continue;
             work.push_back(n);
         }
     }

@@ -50,7 +50,7 @@ def _worker(rank, world, port, n_rows, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])  # 8 = the node size the scaling run uses
 def test_sharded_quantification_gloo(tmp_path, oracle, canopy_lib, world):
     n_rows = 40000
     mp.spawn(_worker, args=(world, _free_port(), n_rows, str(tmp_path)), nprocs=world, join=True)

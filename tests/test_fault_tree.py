@@ -227,3 +227,67 @@ def test_cpp_benchmark_driver_matches_the_python_path(canopy_lib, gpu_ctx, tmp_p
     model.close()
     assert (r["n_kept"], r["argmax_row"], r["rare_event"], r["mcub"]) == (want.n_kept, want.argmax_row, want.rare_event, want.mcub)
     assert r["kernel_ran"] == 5 and r["value"] > 0 and 0 < r["roofline"]["frac"] < 2
+
+
+def random_coherent_mef(rng):
+    """A random coherent tree (and / or / atleast, shared sub-gates, shared events, a house event now and then) as
+    Open-PSA MEF text; gate g may only refer to gates with a larger index -> acyclic; gate 0 is the top."""
+    n_events = int(rng.integers(2, 11))
+    n_gates = int(rng.integers(1, 9))
+    ev = ["e%d" % j for j in range(n_events)]
+    houses = {"h_true": "true", "h_false": "false"} if rng.random() < 0.4 else {}
+    text_gates = []
+    for g in range(n_gates):
+        pool = ev + ["g%d" % k for k in range(g + 1, n_gates)] + list(houses)
+        k = int(rng.integers(2, min(5, len(pool)) + 1))
+        args = list(rng.choice(pool, size=k, replace=False))
+        if g + 1 < n_gates and "g%d" % (g + 1) not in args:
+            args[0] = "g%d" % (g + 1)  # keeps every gate inside the top's cone
+        kind = rng.choice(["and", "or", "atleast"])
+        inner = "".join(ref(a) for a in args)
+        if kind == "atleast":
+            body = "<atleast min='%d'>%s</atleast>" % (int(rng.integers(1, len(args) + 1)), inner)
+        else:
+            body = "<%s>%s</%s>" % (kind, inner, kind)
+        text_gates.append("<define-gate name='g%d'>%s</define-gate>" % (g, body))
+    data = events(ev, 0.1) + "".join("<define-house-event name='%s'><constant value='%s'/></define-house-event>" % kv
+                                     for kv in houses.items())
+    return MEF % ("".join(text_gates), data)
+
+
+def ref(name):
+    if name.startswith("g"):
+        return "<gate name='%s'/>" % name
+    if name.startswith("h_"):
+        return "<house-event name='%s'/>" % name
+    return "<basic-event name='%s'/>" % name
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_coherent_trees_against_truth_tables(canopy_lib, seed):
+    """MOCUS-style lowering vs brute force: the minimal cut sets are the minimal TRUE assignments of the truth table
+    of the exported gate DAG (which itself is checked against the written tree by the fixed cases above)."""
+    from canopy_amd import _capi
+    from canopy_amd.fault_tree import FaultTree
+    rng = np.random.default_rng(77 + seed)
+    text = random_coherent_mef(rng)
+    try:
+        ft = FaultTree(xml_text=text)
+    except _capi.CanopyError as e:  # a tree whose top folds to a constant has no gate left: legal rejection
+        assert e.status in (_capi.ERR_INVALID_MODEL, _capi.ERR_UNSUPPORTED), text
+        return
+    try:
+        dag = ft.dag()
+    except _capi.CanopyError as e:  # the house events decide the top event: constant FALSE (no cut set) or TRUE (the empty one)
+        assert e.status == _capi.ERR_UNSUPPORTED
+        row_ptr, col = ft.cut_sets()
+        assert len(row_ptr) - 1 in (0, 1) and len(col) == 0
+        return
+    p = ft.probabilities()
+    want_sets, _ = brute_force(dag, p)
+    row_ptr, col = ft.cut_sets()
+    assert csr_rows(row_ptr, col) == want_sets, text
+    for i in range(len(row_ptr) - 1):
+        assert np.all(np.diff(col[row_ptr[i]:row_ptr[i + 1]]) > 0)
+    lo = ft.cut_sets(limit_order=2)
+    assert csr_rows(*lo) == [s for s in want_sets if len(s) <= 2]
