@@ -503,13 +503,10 @@ hipError_t launch_fr_filter_t(const uint32_t* stream, const int64_t* fr_off, int
                               int64_t n_rows, int64_t n_slabs, double cand_cut, uint16_t* cand_list, unsigned* cand_cnt,
                               unsigned long long* cand_count, int n_cu, hipStream_t s) {
     using Cf = FrCfg<SLAB_ROWS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter<SLAB_ROWS, U>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // per device and cheap: set on every launch (no process-wide "done" flag: contexts on other devices / threads)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter<SLAB_ROWS, U>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     int64_t grid = (int64_t)n_cu * (SLAB_ROWS > 8192 ? 1 : 2);
     if (grid > n_slabs) grid = n_slabs;
     if (grid < 1) grid = 1;
@@ -556,14 +553,10 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
     static const int u = getenv("CANOPY_FR_QU") ? atoi(getenv("CANOPY_FR_QU")) : 2; // tuning only
     static const int fr_dbg = getenv("CANOPY_FR_DEBUG") ? atoi(getenv("CANOPY_FR_DEBUG")) : 0; // timing ablations only
     const size_t lds = kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16 + (kQ8SlabRows / 64) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    const void* fn = u == 1 ? reinterpret_cast<const void*>(&k_fr_filter_q8<1>)
+                     : u == 4 ? reinterpret_cast<const void*>(&k_fr_filter_q8<4>) : reinterpret_cast<const void*>(&k_fr_filter_q8<2>);
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); // per device: every launch
+    if (e != hipSuccess) return e;
     int64_t grid = n_cu;
     if (grid > n_slabs) grid = n_slabs;
     if (grid < 1) grid = 1;

@@ -518,14 +518,6 @@ canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* d, const ca
         W = w_env;
     const size_t lds = std::max<size_t>(((n_nodes * (size_t)W * 8 + 15) & ~(size_t)15) + (dag_lds ? dag_bytes : 0), 16);
     if (lds > 160 * 1024) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "gate DAG too large for the LDS node array (events + gates <= 20480)");
-    static bool attr_set = false;
-    if (!attr_set) {
-#define MC_ATTR(WW, LL) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mc<WW, LL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-        MC_ATTR(16, true); MC_ATTR(8, true); MC_ATTR(4, true); MC_ATTR(2, true); MC_ATTR(1, true);
-        MC_ATTR(16, false); MC_ATTR(8, false); MC_ATTR(4, false); MC_ATTR(2, false); MC_ATTR(1, false);
-#undef MC_ATTR
-        attr_set = true;
-    }
     McArgs a;
     a.desc = d->d_desc; a.args = d->d_args; a.level_ptr = d->d_level_ptr; a.thresh = d->d_thresh;
     a.n_events = d->n_events; a.n_gates = d->n_gates; a.n_levels = d->n_levels; a.top = d->top; a.n_args = d->n_args; a.n_slots = d->n_slots;
@@ -545,7 +537,12 @@ canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* d, const ca
     if (grid < 1) grid = 1;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_mc_hits, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_mc[0], ctx->stream));
-#define MC_GO(WW, LL) hipLaunchKernelGGL((k_mc<WW, LL>), dim3((unsigned)grid), dim3(kMcThreads), lds, ctx->stream, a)
+// (the LDS attribute is per device: set on every launch, no process-wide flag)
+#define MC_GO(WW, LL)                                                                                                      \
+    do {                                                                                                                   \
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mc<WW, LL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_mc<WW, LL>), dim3((unsigned)grid), dim3(kMcThreads), lds, ctx->stream, a);                    \
+    } while (0)
     if (dag_lds) {
         switch (W) {
             case 16: MC_GO(16, true); break;

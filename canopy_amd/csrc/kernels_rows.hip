@@ -213,16 +213,11 @@ int rows_kernel_default_grid(int n_cu, int variant, int64_t n_rows) {
 }
 
 hipError_t launch_rows_kernel(int variant, const RowKernelArgs& a, int grid, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // the attribute is per device and cheap to set: every launch (no process-wide "done" flag)
+    hipError_t e = hipFuncSetAttribute(variant == CANOPY_KERNEL_ROWS_LDS ? reinterpret_cast<const void*>(&k_rows<true>)
+                                                                         : reinterpret_cast<const void*>(&k_rows<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     if (variant == CANOPY_KERNEL_ROWS_LDS)
         hipLaunchKernelGGL((k_rows<true>), dim3(grid), dim3(kRowsWaves * kWave), RowsLds::total(a.n_events), s, a);
     else

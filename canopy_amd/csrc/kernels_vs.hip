@@ -370,14 +370,11 @@ hipError_t launch_vs_kernel(const RowKernelArgs& ra, const uint32_t* stream, con
     sc.n_rows = ra.n_rows; sc.n_slabs = n_slabs; sc.row_offset = ra.row_offset;
     sc.log_cut = ra.log_cut; sc.limit_order = ra.limit_order;
     static const int dbg = getenv("CANOPY_VS_DEBUG") ? atoi(getenv("CANOPY_VS_DEBUG")) : 0; // timing ablations only
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vs<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vs<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vs<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vs<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    { // per device, cheap: every launch
+        const void* fn = dbg == 1 ? reinterpret_cast<const void*>(&k_vs<1>) : dbg == 2 ? reinterpret_cast<const void*>(&k_vs<2>)
+                         : dbg == 3 ? reinterpret_cast<const void*>(&k_vs<3>) : reinterpret_cast<const void*>(&k_vs<0>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
 #define VS_LAUNCH(A) hipLaunchKernelGGL(k_vs<A>, dim3(grid), dim3(kVsThreads), VsLds::total, s, reinterpret_cast<const uint4*>(stream), vs_off, slab_row, ra.row_ptr, ra.logp, sc, ra.block_partials, ra.row_logp_out, ra.keep_mask_out)
     if (dbg == 1) VS_LAUNCH(1); else if (dbg == 2) VS_LAUNCH(2); else if (dbg == 3) VS_LAUNCH(3); else VS_LAUNCH(0);

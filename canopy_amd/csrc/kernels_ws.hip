@@ -386,13 +386,10 @@ template <int RW, int D, int ABL>
 hipError_t launch_ws_t(const RowKernelArgs& ra, const uint32_t* stream, const int64_t* ws_off, const WsScalars& sc,
                        int grid, hipStream_t s) {
     using C = WsCfg<RW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ws<RW, D, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // per device, cheap: every launch
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ws<RW, D, ABL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_ws<RW, D, ABL>), dim3(grid), dim3(C::waves * kWave), C::lds_bytes, s,
                        reinterpret_cast<const uint4*>(stream), ws_off, ra.logp, ra.row_ptr, sc, ra.block_partials,
                        ra.row_logp_out, ra.keep_mask_out);
