@@ -5,6 +5,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
 #include <new>
 
 #include "canopy_device.h"
@@ -14,8 +15,8 @@ using namespace canopy;
 
 namespace {
 
-uint64_t next_model_id() {
-    static uint64_t counter = 0;
+uint64_t next_model_id() { // contexts may be used from different host threads
+    static std::atomic<uint64_t> counter{0};
     return ++counter;
 }
 
