@@ -112,6 +112,9 @@ SIGNATURES = {
     "canopy_combine_partials": (C.c_int, [C.POINTER(Partial), C.c_int32, C.c_uint32, C.POINTER(QuantResult)]),
     "canopy_fetch_row_logp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "canopy_fetch_keep_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "canopy_graph_capture": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QuantParams), C.POINTER(C.c_void_p)]),
+    "canopy_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "canopy_graph_free": (None, [C.c_void_p]),
     "canopy_fetch_importance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "canopy_ctx_set_importance_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "canopy_quantify_batch_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(QuantParams), C.c_uint32,

@@ -544,7 +544,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     a.keep_mask_out = want_mask ? ctx->d_keep_mask : nullptr;
 
     hipEvent_t* ev = ctx->ev_last;
-    if (ctx->timing_on && ctx->timing_n < ctx->timing_max) {
+    if (ctx->timing_on && !ctx->capturing && ctx->timing_n < ctx->timing_max) {
         ev = &ctx->ev_pool[(size_t)ctx->timing_n * 3];
         ++ctx->timing_n;
     }
@@ -553,7 +553,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         if (want_mask) // slabs start at arbitrary rows: the kernel ORs partial words into a cleared mask
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
     }
-    HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+    if (!ctx->capturing) HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
     if (variant == CANOPY_KERNEL_FILTER_REFINE) {
         // delta covers the rounding difference between the unordered pass-A sum and the CSR-order sum
         const double cand_cut = a.log_cut - (1e-9 + 1e-11 * (double)m->max_row_len);
@@ -587,7 +587,8 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             canopy_model* mm = const_cast<canopy_model*>(m);
             if (!mm->d_q8) HIP_TRY(ctx, hipMalloc(&mm->d_q8, (((size_t)m->n_events + 15) / 16) * 16 + 16));
             // the 8-bit table depends on (logp, cut-off) only: rebuilt when either changed
-            const bool table_valid = mm->q8_version == m->logp_version && mm->q8_version != 0 && mm->q8_log_cut == a.log_cut;
+            const bool table_valid = !ctx->capturing && mm->q8_version == m->logp_version && mm->q8_version != 0 &&
+                                     mm->q8_log_cut == a.log_cut; // (a captured pass always rebuilds it: p may change between replays)
             HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, mm->d_q8, m->n_rows,
                                              m->n_events, m->n_fr_slabs, a.log_cut, ctx->d_fr_list, ctx->d_fr_cnt, ctx->d_fr_count,
                                              ctx->n_cu, table_valid, ctx->stream));
@@ -609,18 +610,18 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     } else {
         HIP_TRY(ctx, launch_rows_kernel(variant, a, grid, ctx->stream));
     }
-    HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
+    if (!ctx->capturing) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     HIP_TRY(ctx, launch_finalize(ctx->d_block_partials, n_records, ctx->d_partial, ctx->d_gather, ctx->gather_world,
                                  ctx->gather_rank, variant == CANOPY_KERNEL_FILTER_REFINE ? ctx->d_fr_count : nullptr, ctx->stream));
     ctx->last_variant = variant;
-    HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
+    if (!ctx->capturing) HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     if (want_imp) { // after the timed pass: one walk over the kept rows
         double* dst = ctx->ext_importance ? ctx->ext_importance : ctx->d_importance;
         HIP_TRY(ctx, hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(m->n_events > 0 ? m->n_events : 1), ctx->stream));
         HIP_TRY(ctx, launch_importance(ctx->d_keep_mask, m->n_rows, m->d_row_ptr, m->d_col_idx, m->d_logp, dst, ctx->stream));
     }
     ctx->last_has_importance = want_imp;
-    if (ev == ctx->ev_last) ctx->last_timed = true;
+    if (ev == ctx->ev_last) ctx->last_timed = !ctx->capturing;
     ctx->last_has_row_logp = want_rows;
     ctx->last_has_mask = (params->flags & CANOPY_QUANT_KEEP_MASK) != 0;
     return CANOPY_OK;
@@ -737,6 +738,57 @@ canopy_status canopy_ctx_set_importance_buffer(canopy_ctx* ctx, void* device_buf
     ctx->ext_importance = static_cast<double*>(device_buffer);
     ctx->ext_importance_n = device_buffer ? n_events : 0;
     return CANOPY_OK;
+}
+
+// ---- captured passes ----------------------------------------------------------------------------------------
+
+canopy_status canopy_graph_capture(canopy_ctx* ctx, const canopy_model* m, const canopy_quant_params* params, canopy_graph** out) {
+    if (!ctx || !m || !out) return CANOPY_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    // one ordinary pass first: lazy layouts, scratch buffers and AUTO's choice are settled outside the capture
+    canopy_status st = canopy_quantify_async(ctx, m, params);
+    if (st != CANOPY_OK) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    canopy_graph* g = new (std::nothrow) canopy_graph();
+    if (!g) return CANOPY_ERR_OUT_OF_MEMORY;
+    g->device = ctx->device;
+    g->model_id = m->id;
+    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { delete g; (void)hipGetLastError(); return fail(ctx, CANOPY_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
+    ctx->capturing = true;
+    st = canopy_quantify_async(ctx, m, params);
+    ctx->capturing = false;
+    e = hipStreamEndCapture(ctx->stream, &g->graph);
+    if (st == CANOPY_OK && e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (st != CANOPY_OK || e != hipSuccess) {
+        (void)hipGetLastError();
+        canopy_graph_free(g);
+        return st != CANOPY_OK ? st : fail(ctx, CANOPY_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(e));
+    }
+    g->variant = ctx->last_variant;
+    g->has_row_logp = ctx->last_has_row_logp; g->has_mask = ctx->last_has_mask; g->has_importance = ctx->last_has_importance;
+    *out = g;
+    return CANOPY_OK;
+}
+
+canopy_status canopy_graph_launch(canopy_ctx* ctx, canopy_graph* g) {
+    if (!ctx || !g || !g->exec) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (g->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "graph was captured on another device");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipGraphLaunch(g->exec, ctx->stream));
+    ctx->last_variant = g->variant;
+    ctx->last_has_row_logp = g->has_row_logp; ctx->last_has_mask = g->has_mask; ctx->last_has_importance = g->has_importance;
+    ctx->last_timed = false;
+    ctx->fr_pending_id = 0; // the candidate-count feedback belongs to eager passes
+    return CANOPY_OK;
+}
+
+void canopy_graph_free(canopy_graph* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
 }
 
 // ---- timing region -----------------------------------------------------------------------------

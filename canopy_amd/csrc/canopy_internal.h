@@ -67,7 +67,18 @@ struct canopy_ctx {
     // batched quantification (lazily created)
     canopy::BatchState* batch = nullptr;
 
+    bool capturing = false; // inside canopy_graph_capture: no timing events, derived tables always rebuilt
+
     std::string last_error;
+};
+
+struct canopy_graph {
+    int device = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t model_id = 0;
+    int32_t variant = 0;
+    bool has_row_logp = false, has_mask = false, has_importance = false;
 };
 
 struct canopy_dag {

@@ -101,6 +101,20 @@ class Context:
         return QuantResult(res.rare_event, res.mcub, res.n_kept, res.argmax_row, res.max_logp,
                            res.elapsed_kernel_ms)
 
+    # -- captured passes (hipGraph) ----------------------------------------------------------------
+    def graph_capture(self, model, params=None):
+        g = C.c_void_p()
+        capi.check(capi.lib().canopy_graph_capture(self._h, model.handle, C.byref(params) if params else None, C.byref(g)),
+                   "canopy_graph_capture", self._h)
+        return g
+
+    def graph_launch(self, graph):
+        capi.check(capi.lib().canopy_graph_launch(self._h, graph), "canopy_graph_launch", self._h)
+
+    @staticmethod
+    def graph_free(graph):
+        capi.lib().canopy_graph_free(graph)
+
     def fetch_importance(self, model):
         """contrib[j] = sum of P_i over kept cut sets containing event j (last pass with QUANT_IMPORTANCE)."""
         out = np.empty(model.info().n_events, dtype=np.float64)

@@ -287,6 +287,21 @@ CANOPY_API canopy_status canopy_last_kernel_ms(canopy_ctx* ctx, double* row_kern
    resolved to); 0 before the first pass. */
 CANOPY_API int32_t canopy_last_kernel_variant(const canopy_ctx* ctx);
 
+/* ---- captured passes (hipGraph) -------------------------------------------------------------------------- */
+/*
+ * A small model is launch-bound (config 2: 1e5 cut sets, ~10 us of kernel time in 2-4 launches). canopy_graph_capture
+ * records the launches canopy_quantify_async would enqueue for (model, params) into a HIP graph; canopy_graph_launch
+ * replays them with ONE launch on the context's stream. Results are fetched as usual (canopy_quantify_fetch, the
+ * gather buffer, canopy_fetch_keep_mask ...). The probabilities may be changed between launches
+ * (canopy_model_set_probabilities writes the same device buffer); per-launch timing is not available for a replay.
+ * The context, the model and its derived layouts must outlive the graph; capture once per (model, params).
+ */
+typedef struct canopy_graph canopy_graph;
+CANOPY_API canopy_status canopy_graph_capture(canopy_ctx* ctx, const canopy_model* model,
+                                              const canopy_quant_params* params, canopy_graph** out);
+CANOPY_API canopy_status canopy_graph_launch(canopy_ctx* ctx, canopy_graph* graph);
+CANOPY_API void canopy_graph_free(canopy_graph* graph);
+
 /* ---- N4: batched quantification -- K probability vectors ("trials") against one model ------------- */
 /*
  * Reference vocabulary: uncertainty analysis quantifies the same cut sets under num_trials sampled

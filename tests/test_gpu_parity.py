@@ -337,3 +337,30 @@ def test_filter_refine_rows_on_the_cut_off_boundary(gpu_ctx, oracle):
                 assert np.array_equal(gpu_ctx.fetch_keep_mask(model), want.keep_mask), (q, cut, kern)
                 assert rel(got.rare_event, want.rare_event) < TOL
     model.close()
+
+
+def test_captured_pass_replays_like_an_eager_one(gpu_ctx, oracle):
+    """canopy_graph_capture / canopy_graph_launch: same record as the eager pass, also after the probabilities changed
+    between replays, for a one-kernel variant and for filter/refine (whose quantised table is rebuilt inside the graph)."""
+    import canopy_amd
+    from canopy_amd import _capi
+    for n_rows, n_events, avg, flags in ((60_000, 900, 4, _capi.QUANT_KEEP_MASK), (1_100_000, 30_000, 6, 0)):
+        p = canopy_amd.synthetic_probabilities(SEED, n_events)
+        model = gpu_ctx.synthetic(SEED, n_rows, n_events, avg)
+        model.set_probabilities(p)
+        prm = canopy_amd.default_params(flags=flags)
+        g = gpu_ctx.graph_capture(model, prm)
+        try:
+            for scale in (1.0, 0.5, 2.0):
+                model.set_probabilities(np.minimum(1.0, p * scale))
+                want = gpu_ctx.quantify(model, prm)
+                want_mask = gpu_ctx.fetch_keep_mask(model) if flags else None
+                gpu_ctx.graph_launch(g)
+                got = canopy_amd.combine_partials([gpu_ctx.fetch_partial()])
+                assert (got.rare_event, got.mcub, got.n_kept, got.argmax_row, got.max_logp) == \
+                       (want.rare_event, want.mcub, want.n_kept, want.argmax_row, want.max_logp)
+                if flags:
+                    assert np.array_equal(gpu_ctx.fetch_keep_mask(model), want_mask)
+        finally:
+            gpu_ctx.graph_free(g)
+            model.close()
