@@ -60,8 +60,8 @@ def cpu_baseline(ctx, canopy_amd, n_events, avg, p, sample_rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows-per-gpu", type=int, default=100_000_000)
     ap.add_argument("--events", type=int, default=100_000)
     ap.add_argument("--avg-nnz", type=int, default=6)
