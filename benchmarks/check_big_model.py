@@ -1,0 +1,21 @@
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch
+import canopy_amd, oracle_py
+SEED, N, E, AVG = 20250704, int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000, 100_000, 6
+cores = len(os.sched_getaffinity(0))
+p = canopy_amd.synthetic_probabilities(SEED, E)
+ctx = canopy_amd.Context(device=0)
+m = ctx.synthetic(SEED, N, E, AVG); m.set_probabilities(p)
+got = ctx.quantify(m, canopy_amd.default_params())
+print("gpu", got.n_kept, got.argmax_row, got.rare_event, got.mcub, "variant", ctx.last_kernel_variant(), flush=True)
+t0 = time.time()
+rp, col = oracle_py.synth_csr(SEED, N, E, AVG, n_threads=cores)
+print("oracle synth s", time.time() - t0, "nnz", int(rp[-1]), flush=True)
+t0 = time.time()
+w = oracle_py.quantify(rp, col, p, n_threads=cores, want_rows=False)
+print("oracle quantify s", time.time() - t0, int(w.n_kept), int(w.argmax_row), w.rare_event, w.mcub, flush=True)
+ok = got.n_kept == int(w.n_kept) and got.argmax_row == int(w.argmax_row) and got.max_logp == w.max_logp \
+     and abs(got.rare_event - w.rare_event) <= 1e-12 * w.rare_event and abs(got.mcub - w.mcub) <= 1e-12 * w.mcub
+print("MATCH" if ok else "MISMATCH")
