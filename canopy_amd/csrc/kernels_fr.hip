@@ -301,6 +301,19 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int64_t G = (int64_t)gridDim.x;
+    // the first chunks of a slab are requested BEFORE the workgroup-wide steps in front of it (table staging here,
+    // the previous slab's end step in the loop): no slab starts with a cold stream
+    uint4 q[U];
+#define FR_FIRST_CHUNKS(SLAB)                                                                       \
+    if ((SLAB) < n_slabs) {                                                                         \
+        const int64_t f0 = fr_uload(fr_off + (SLAB)), f1 = fr_uload(fr_off + (SLAB) + 1);           \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                             \
+            const int64_t c = f0 + wave + (int64_t)u * kQ8Waves;                                    \
+            q[u] = stream[(c < f1 ? c : total_chunks) * kWave + lane];                              \
+        }                                                                                           \
+    }
+    FR_FIRST_CHUNKS((int64_t)blockIdx.x)
     for (int i = tid; i < kQ8SlabRows + 64; i += kQ8Threads) sums[i] = 0u;
     { // the table, 16 bytes per lane per step (its buffer is padded to a multiple of 16)
         const uint4* src = reinterpret_cast<const uint4*>(q8);
@@ -310,15 +323,9 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
     fr_barrier();
 
     unsigned long long n_cand = 0;
-    const int64_t G = (int64_t)gridDim.x;
     for (int64_t s = (int64_t)blockIdx.x; s < n_slabs; s += G) {
         const int64_t c0 = fr_uload(fr_off + s), c1 = fr_uload(fr_off + s + 1);
-        uint4 q[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t c = c0 + wave + (int64_t)u * kQ8Waves;
-            q[u] = stream[(c < c1 ? c : total_chunks) * kWave + lane];
-        }
+        if (abl & 16) { FR_FIRST_CHUNKS(s) } // A/B switch (CANOPY_FR_DEBUG=16): the slab's first chunks requested only now
         for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * kQ8Waves) {
             uint4 qn[U]; // next step's chunks first: nothing else is in the vector-memory queue
 #pragma unroll
@@ -350,6 +357,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
 #pragma unroll
             for (int u = 0; u < U; ++u) q[u] = qn[u];
         }
+        if (!(abl & 16)) { FR_FIRST_CHUNKS(s + G) } // the next slab's stream starts under this slab's end step
         fr_barrier();
         const int64_t r0 = s * kQ8SlabRows;
         constexpr int NI = kQ8SlabRows / kQ8Threads;
@@ -371,6 +379,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
         if (tid == 0) cand_cnt[s] = total;
         n_cand += total; // workgroup-uniform
     }
+#undef FR_FIRST_CHUNKS
     if (tid == 0 && n_cand) atomicAdd(cand_count, n_cand); // one global atomic per workgroup, as in k_fr_filter
 }
 
