@@ -7,6 +7,6 @@ R=$PWD
 mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${TAG}_stats" -o fr -- \
-  python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$R/gpurun_out/${TAG}_stats.log" 2>&1
+  python3 "$R/bench.py" --no-cpu-baseline > "$R/gpurun_out/${TAG}_stats.log" 2>&1
 cd "$R"
 timeout -k 10 500 python bench.py > "gpurun_out/${TAG}_bench.json" 2> "gpurun_out/${TAG}_bench.err"

@@ -559,18 +559,21 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    static const int u = getenv("CANOPY_FR_QU") ? atoi(getenv("CANOPY_FR_QU")) : 2; // tuning only
+    static const int u = getenv("CANOPY_FR_QU") ? atoi(getenv("CANOPY_FR_QU")) : 4; // tuning only (chunks in flight per wave)
     static const int fr_dbg = getenv("CANOPY_FR_DEBUG") ? atoi(getenv("CANOPY_FR_DEBUG")) : 0; // timing ablations only
     const size_t lds = kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16 + (kQ8SlabRows / 64) * 4;
-    const void* fn = u == 1 ? reinterpret_cast<const void*>(&k_fr_filter_q8<1>)
-                     : u == 4 ? reinterpret_cast<const void*>(&k_fr_filter_q8<4>) : reinterpret_cast<const void*>(&k_fr_filter_q8<2>);
+    const void* fn = u == 1   ? reinterpret_cast<const void*>(&k_fr_filter_q8<1>)
+                     : u == 2 ? reinterpret_cast<const void*>(&k_fr_filter_q8<2>)
+                     : u == 3 ? reinterpret_cast<const void*>(&k_fr_filter_q8<3>)
+                     : u == 6 ? reinterpret_cast<const void*>(&k_fr_filter_q8<6>)
+                              : reinterpret_cast<const void*>(&k_fr_filter_q8<4>);
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); // per device: every launch
     if (e != hipSuccess) return e;
     int64_t grid = n_cu;
     if (grid > n_slabs) grid = n_slabs;
     if (grid < 1) grid = 1;
 #define Q8_GO(UU) hipLaunchKernelGGL(k_fr_filter_q8<UU>, dim3((unsigned)grid), dim3(kQ8Threads), lds, s, reinterpret_cast<const uint4*>(stream), fr_off, total_chunks, q8_buf, n_events, n_rows, n_slabs, threshold, cand_list, cand_cnt, cand_count, fr_dbg)
-    if (u == 1) Q8_GO(1); else if (u == 4) Q8_GO(4); else Q8_GO(2);
+    if (u == 1) Q8_GO(1); else if (u == 2) Q8_GO(2); else if (u == 3) Q8_GO(3); else if (u == 6) Q8_GO(6); else Q8_GO(4);
 #undef Q8_GO
     return hipGetLastError();
 }
