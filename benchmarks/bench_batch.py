@@ -35,9 +35,10 @@ def main():
     model.set_probabilities(p)
     prm = canopy_amd.default_params()
     model.prepare(0)
-    for _ in range(3):
-        ctx.quantify(model, prm)
-    single_ms = min(ctx.quantify(model, prm).elapsed_kernel_ms for _ in range(5))
+    for _ in range(60):  # spin-up: the first ~20 launches after the idle model build run through a clock transient
+        ctx.quantify_async(model, prm)
+    ctx.synchronize()
+    single_ms = float(np.median([ctx.quantify(model, prm).elapsed_kernel_ms for _ in range(9)]))
     for sigma in [float(x) for x in args.sigmas.split(",")]:
         for k in [int(x) for x in args.trials.split(",")]:
             rng = np.random.default_rng(1234)
