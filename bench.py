@@ -58,6 +58,11 @@ def cpu_baseline(ctx, canopy_amd, n_events, avg, p, sample_rows):
 
 
 def main():
+    # Contract: rank 0 prints ONE JSON line on stdout. Native libraries write there too (RCCL prints a version banner
+    # at communicator init), so file descriptor 1 points at stderr for the whole run and the line goes to the saved fd.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -206,7 +211,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ctx, canopy_amd, args.events, args.avg_nnz, p, args.cpu_sample_rows)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     model.close()
     if comb is not None:

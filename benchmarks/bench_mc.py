@@ -14,6 +14,9 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    sys.stdout.flush()
+    json_fd = os.dup(1)  # native libraries (RCCL's version banner) write to fd 1: keep stdout to the one JSON line
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=1_000_000_000)
     ap.add_argument("--events", type=int, default=100)
@@ -54,14 +57,14 @@ def main():
         elapsed = float(t.item())
     if rank == 0:
         n_gates = len(dag["gate_type"]); total = per_rank * world
-        print(json.dumps({"metric": "Monte-Carlo samples/sec", "value": total * args.steps / elapsed, "unit": "samples/s",
+        os.write(json_fd, (json.dumps({"metric": "Monte-Carlo samples/sec", "value": total * args.steps / elapsed, "unit": "samples/s",
                           "n_gpus": world, "steps": args.steps, "ms_per_step": elapsed * 1e3 / args.steps,
                           "kernel_ms": ms / args.steps, "dtype": "u64 bit-packed", "data": "synthetic",
                           "config": {"workload": "layered AND/OR/K-of-N DAG", "samples": total, "n_events": args.events,
                                      "n_gates": n_gates, "fan_in": args.fan_in, "layers": args.layers},
                           "event_draws_per_s": total * args.events * args.steps / elapsed,
                           "gate_evals_per_s": total * n_gates * args.steps / elapsed,
-                          "estimate": int(hits.item()) / total, "hits": int(hits.item())}))
+                          "estimate": int(hits.item()) / total, "hits": int(hits.item())}) + "\n").encode())
     d.close(); ctx.close()
     if world > 1:
         dist.destroy_process_group()
