@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, else a CANOPY_KERNEL_* id")
     ap.add_argument("--cpu-sample-rows", type=int, default=20_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-backend", default="",
+                    help="rehearsal only: process-group backend other than nccl (gloo) with every rank on GPU "
+                         "LOCAL_RANK %% device_count -- lets a one-GPU box run the N>1 code path")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearse the N>1 code path (process group, gather buffer, all-reduce) at world size 1")
     args = ap.parse_args()
@@ -94,6 +97,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the quantification path")
+    if args.rehearse_backend:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -101,7 +106,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if args.rehearse_backend:
+            dist.init_process_group(args.rehearse_backend)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
     # One stream carries the kernels AND the collective: a dedicated (non-default) torch stream whose
     # raw hipStream_t is handed to the library (a NULL handle would make the library create its own).
