@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- quantified cut-sets/sec of the hot path on N MI355X (BASELINE.json metric).
 
-A "step" is one quantification pass (row kernel + final reduce, + the single RCCL all-reduce of
-the shard partials at N>1) over the synthetic CSR resident in HBM. Workload at every N: each rank
-holds ROWS_PER_GPU = 1e8 cut sets x 1e5 basic events, avg 6 nnz/row, fp64 (BASELINE config 3 per
-GPU; at N GPUs the model is N*1e8 rows, row-sharded -> weak scaling). Rank r owns global rows
-[r*1e8, (r+1)*1e8) of the same counter-based family (seed 20250704).
+A "step" is one quantification pass over the synthetic CSR resident in HBM: row kernels + final reduce and,
+at N > 1, the single RCCL all-reduce of the shard partials -- issued by libcanopy.so itself on the pass's stream
+(canopy_comm_*, no Python between kernel and collective).
+
+Workload. N = 1: BASELINE config 3 -- 1e8 cut sets x 1e5 basic events, avg 6 nnz/row, fp64.
+N > 1 (default, `--scaling strong`): BASELINE config 4 -- the SAME 1e8-row model row-sharded N ways,
+contiguous nnz-balanced shards (canopy_shard_rows' rule); rank r generates only its own shard of the counter-based
+family (seed 20250704). `--scaling weak` is the opt-in: every rank holds --rows rows of an N x --rows model.
 
 Launch: `python bench.py --gpus 1 --steps K --warmup W`, or for N>1
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...`.
-Prints ONE JSON line on rank 0.
+torch.distributed (gloo) is the control plane only: it hands out libcanopy's RCCL id, runs the barriers and the
+MAX over ranks of the timed region. Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -29,7 +33,6 @@ def cpu_baseline(ctx, canopy_amd, n_events, avg, p, sample_rows):
     (rows [0, sample_rows) of the family). Build-authored baseline ("port"): the reference has no
     CPU quantifier to time (reference src/canopy.cpp:1-31 holds no code)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
     import oracle_py
     cores = len(os.sched_getaffinity(0))
     row_ptr, col = oracle_py.synth_csr(SEED, sample_rows, n_events, avg, n_threads=cores)
@@ -57,6 +60,21 @@ def cpu_baseline(ctx, canopy_amd, n_events, avg, p, sample_rows):
     }
 
 
+KERNEL_LABELS = {1: "k_rows (lane per row, L2 gather)", 2: "k_rows (lane per row, LDS table)",
+                 3: "k_ws (wave-slab stream, exact CSR-order sums)", 4: "k_vs (value scatter)",
+                 5: "k_fr_filter_q8 + k_fr_refine (quantised conservative filter, then exact refine)",
+                 6: "k_fx_sum + k_fr_refine (order-independent fixed-point sums, exact refine of the undecided rows)"}
+
+
+def stats(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    if n == 0:
+        return None, None, None
+    med = xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+    return sum(xs) / n, med, xs[0]
+
+
 def main():
     # Contract: rank 0 prints ONE JSON line on stdout. Native libraries write there too (RCCL prints a version banner
     # at communicator init), so file descriptor 1 points at stderr for the whole run and the line goes to the saved fd.
@@ -71,24 +89,33 @@ def main():
                     help="untimed passes right after the model build, before the warm-up steps: the GPU idles while the model "
                          "is generated and its first ~20 launches run through a clock / power transient (filter launch 450 us "
                          "decaying to the steady 380 us: profiles/r01_filter_launch_sequence.txt)")
-    ap.add_argument("--rows-per-gpu", type=int, default=100_000_000)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong (default): --rows is the WHOLE model, sharded over the ranks (BASELINE config 4); "
+                         "weak: --rows per rank")
+    ap.add_argument("--rows", "--rows-per-gpu", dest="rows", type=int, default=100_000_000)
     ap.add_argument("--events", type=int, default=100_000)
     ap.add_argument("--avg-nnz", type=int, default=6)
     ap.add_argument("--cut-off", type=float, default=1e-8)
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, else a CANOPY_KERNEL_* id")
     ap.add_argument("--cpu-sample-rows", type=int, default=20_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the cut_off = 0 leg (N = 1 only)")
+    ap.add_argument("--also-steps", type=int, default=30)
+    ap.add_argument("--collective", choices=("lib", "torch"), default="lib",
+                    help="lib: canopy_comm_* (ncclAllReduce issued by libcanopy.so); torch: torch.distributed all_reduce")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="single-GPU rehearsal of a strong-scaling shard: run shard 0 of an N-way split of --rows")
     ap.add_argument("--rehearse-backend", default="",
-                    help="rehearsal only: process-group backend other than nccl (gloo) with every rank on GPU "
+                    help="rehearsal only: torch collective over this backend (gloo) with every rank on GPU "
                          "LOCAL_RANK %% device_count -- lets a one-GPU box run the N>1 code path")
     ap.add_argument("--force-dist", action="store_true",
-                    help="rehearse the N>1 code path (process group, gather buffer, all-reduce) at world size 1")
+                    help="rehearse the N>1 code path (communicator, gather slots, all-reduce) at world size 1")
     args = ap.parse_args()
 
     import torch  # first: one HIP runtime shared in-process
     import torch.distributed as dist
     import canopy_amd
-    from canopy_amd.distributed import ShardCombiner
+    from canopy_amd.distributed import ShardCombiner, library_comm
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -99,6 +126,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the quantification path")
     if args.rehearse_backend:
         local_rank = local_rank % torch.cuda.device_count()
+        args.collective = "torch"
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -106,34 +134,64 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.rehearse_backend:
-            dist.init_process_group(args.rehearse_backend)
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        dist.init_process_group("gloo")  # control plane only
 
-    # One stream carries the kernels AND the collective: a dedicated (non-default) torch stream whose
-    # raw hipStream_t is handed to the library (a NULL handle would make the library create its own).
+    # One stream carries the kernels AND the collective.
     tstream = torch.cuda.Stream(device=local_rank) if use_dist else None
     ctx = canopy_amd.Context(device=local_rank, stream=tstream.cuda_stream if tstream is not None else None)
+
+    # ---- the collective: libcanopy's own RCCL communicator; torch's only if that cannot be set up ----
+    comm, comb, collective, torch_group = None, None, "none (single GPU)", None
+    if use_dist:
+        err = ""
+        if args.collective == "lib":
+            try:
+                comm = library_comm(ctx)
+            except Exception as e:  # noqa: BLE001 -- reported in the line, then the fallback
+                err = repr(e)
+            flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:  # some rank failed: every rank falls back together
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                sys.stderr.write("[bench] canopy_comm_init_rank failed (%s): falling back to torch.distributed\n" % err)
+        if comm is not None:
+            collective = "ncclAllReduce of %d B issued by libcanopy.so (canopy_comm, RCCL %d)" % (world * 64, comm.rccl_version())
+        else:
+            backend = args.rehearse_backend or "nccl"
+            torch_group = dist.new_group(backend=backend)
+            comb = ShardCombiner(ctx=ctx, group=torch_group)
+            collective = "torch.distributed all_reduce of %d B (%s)%s" % (world * 64, backend,
+                                                                         " [fallback: %s]" % err if err else "")
+
+    # ---- the model: this rank's shard ----
     p = canopy_amd.synthetic_probabilities(SEED, args.events)
     t0 = time.time()
-    model = ctx.synthetic(SEED, args.rows_per_gpu, args.events, args.avg_nnz, first_row=rank * args.rows_per_gpu)
+    n_shards = world if args.shard_of <= 0 else args.shard_of
+    if args.scaling == "strong" and n_shards > 1:
+        total_rows = args.rows
+        bounds = canopy_amd.synthetic_shard_bounds(ctx, SEED, total_rows, args.avg_nnz, n_shards)
+        k = rank if args.shard_of <= 0 else 0
+        first_row, my_rows = int(bounds[k]), int(bounds[k + 1] - bounds[k])
+    else:
+        total_rows = args.rows * world
+        first_row, my_rows = rank * args.rows, args.rows
+    model = ctx.synthetic(SEED, my_rows, args.events, args.avg_nnz, first_row=first_row)
     model.set_probabilities(p)
-    info = model.info()
     t_build = time.time() - t0
     prm = canopy_amd.default_params(cut_off=args.cut_off, limit_order=20, kernel=args.kernel)
     t0 = time.time()
-    model.prepare(args.kernel)  # one-off derived layout (wave-slab stream) for the variant that will run
+    model.prepare(args.kernel)  # one-off derived layout for the variant that will run
     ctx.synchronize()
     t_prepare = time.time() - t0
     info = model.info()
-    comb = ShardCombiner(ctx=ctx) if use_dist else None
 
     def step():
-        ctx.quantify_async(model, prm)
+        ctx.quantify_async(model, prm)  # with a canopy_comm attached this ends with the all-reduce
         if comb is not None:
             with torch.cuda.stream(tstream):
-                comb.all_reduce(force=args.force_dist)  # K5: the one collective, same stream as the kernels
+                comb.all_reduce(force=args.force_dist)
 
     def fence():
         ctx.synchronize()
@@ -143,7 +201,7 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.spinup):  # setup, like the model build: not a warm-up step, not timed
-        ctx.quantify_async(model, prm)
+        step()
     ctx.synchronize()
     for _ in range(args.warmup):
         step()
@@ -152,33 +210,73 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enqueued = time.perf_counter() - t0
     ctx.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     k_ms_sum, tot_ms_sum, n_timed = ctx.timing_end()
+    launches = ctx.timing_launches(n_timed)
 
-    if comb is not None:
+    if comm is not None:
+        result = comm.fetch()
+    elif comb is not None:
         with torch.cuda.stream(tstream):
             result = comb.result()
     else:
         result = canopy_amd.combine_partials([ctx.fetch_partial()])
+    ctx.fetch_partial()  # AUTO feedback + candidate count of the last pass
+    cand = ctx.last_filter_candidates()
 
     variant = ctx.last_kernel_variant()  # what AUTO resolved to, reported by the library
-    kernel_label = {1: "k_rows (lane per row, L2 gather)", 2: "k_rows (lane per row, LDS table)",
-                    3: "k_ws (wave-slab stream)", 4: "k_vs (value scatter)",
-                    5: "k_fr_filter_q8 + k_fr_refine (quantised conservative filter, then exact refine)"
-                    if info.n_events <= 112 * 1024 else "k_fr_filter + k_fr_refine (filter, then exact refine)"}[variant]
+    kernel_label = KERNEL_LABELS.get(variant, "?")
+    if variant == 5 and info.n_events > 112 * 1024:
+        kernel_label = "k_fr_filter + k_fr_refine (gathered fp64 filter, then exact refine)"
+
+    info = model.info()  # (before the all-rows leg adds its own layout to device_bytes)
+
+    # ---- the pure-bandwidth leg, cut_off = 0 (every row through exp / log1p), same run, N = 1 ----
+    also = None
+    if world == 1 and not args.no_also and not args.force_dist:
+        prm0 = canopy_amd.default_params(cut_off=0.0, limit_order=20, kernel=0)
+        t0 = time.time()
+        ctx.quantify_async(model, prm0)  # builds the layout of the all-rows kernel on first use
+        ctx.synchronize()
+        t_prep0 = time.time() - t0
+        for _ in range(5):
+            ctx.quantify_async(model, prm0)
+        ctx.synchronize()
+        ctx.timing_begin(args.also_steps)
+        t0 = time.perf_counter()
+        for _ in range(args.also_steps):
+            ctx.quantify_async(model, prm0)
+        ctx.synchronize()
+        el0 = time.perf_counter() - t0
+        _, _, n0 = ctx.timing_end()
+        l0 = ctx.timing_launches(n0)
+        r0 = canopy_amd.combine_partials([ctx.fetch_partial()])
+        v0 = ctx.last_kernel_variant()
+        k_mean, k_med, k_min = stats([a for a, _ in l0])
+        p_mean, p_med, p_min = stats([b for _, b in l0])
+        also = {"cut_off_0": {
+            "ms_per_step": el0 * 1e3 / args.also_steps, "steps": args.also_steps,
+            "kernel_ran": v0, "kernel": KERNEL_LABELS.get(v0, "?"),
+            "kernel_ms": {"mean": k_mean, "median": k_med, "min": k_min},
+            "pass_ms": {"mean": p_mean, "median": p_med, "min": p_min},
+            "frac": info.algorithmic_bytes / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "cut_sets_per_s": info.n_rows * args.also_steps / el0,
+            "n_kept": r0.n_kept, "rare_event": r0.rare_event, "mcub": r0.mcub, "layout_build_s": t_prep0,
+        }}
     if rank == 0:
-        total_rows = info.n_rows * world
         ms_per_step = elapsed * 1e3 / args.steps
-        k_ms = k_ms_sum / max(n_timed, 1)
-        achieved = info.algorithmic_bytes / (k_ms * 1e-3) / 1e9
+        k_mean, k_med, k_min = stats([a for a, _ in launches])
+        p_mean, p_med, p_min = stats([b for _, b in launches])
+        achieved = info.algorithmic_bytes / (k_mean * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (benchmarks/pmc.sh): only quoted
         # when they were collected for the kernel and workload that just ran
         traffic = None
@@ -191,41 +289,61 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        cand_frac = (cand[0] / cand[1]) if (cand and cand[1] and variant == 5) else None
         line = {
             "metric": "quantified cut-sets/sec", "value": total_rows * args.steps / elapsed, "unit": "cut-sets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_passes": args.spinup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
             "config": {
-                "workload": "synthetic CSR %.0e cut-sets x %.0e basic events per GPU, avg %d nnz/row, fp64, "
-                            "rare-event + MCUB, cut_off %g" % (info.n_rows, info.n_events, args.avg_nnz, args.cut_off),
-                "rows_per_gpu": info.n_rows, "nnz_per_gpu": info.nnz, "n_events": info.n_events,
-                "sharding": "row-sharded, %d rank(s), one all-reduce of %d B" % (world, world * 64) if world > 1
-                else "single GPU, no collective",
+                "workload": "synthetic CSR %.3g cut-sets x %.0e basic events in all (%s: %.4g rows on this rank), avg %d nnz/row, "
+                            "fp64, rare-event + MCUB, cut_off %g%s"
+                            % (total_rows, info.n_events,
+                               "one GPU" if world == 1 else "%s scaling over %d ranks" % (args.scaling, world),
+                               info.n_rows, args.avg_nnz, args.cut_off,
+                               "; %.2f %% of the rows pass the conservative filter into the exact pass, %.2f %% survive the cut-off"
+                               % (100 * cand_frac, 100.0 * result.n_kept / max(total_rows, 1)) if cand_frac is not None else ""),
+                "total_rows": total_rows, "rows_this_rank": info.n_rows, "first_row_this_rank": first_row,
+                "nnz_this_rank": info.nnz, "n_events": info.n_events,
+                "sharding": ("contiguous nnz-balanced row shards (canopy_shard_rows rule), %d rank(s); " % world + collective)
+                if use_dist else "single GPU, no collective",
                 "seed": SEED, "kernel": args.kernel, "kernel_ran": variant,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac_real": (traffic / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "note": "achieved/frac = SURVEY 8(d) ALGORITHMIC bytes (canonical CSR, 32 B per cut set) / kernel time: an "
+                        "equivalent rate, not bytes moved -- the filter streams a 24.1 B-per-cut-set re-encoding; frac_real = "
+                        "PMC-measured HBM bytes / kernel time / peak. Both hold while few rows pass the filter (config.workload); "
+                        "see also.cut_off_0 for the all-rows case",
                 "kernel": kernel_label,
                 "algorithmic_bytes_per_launch": info.algorithmic_bytes,
                 "bytes_per_cut_set": info.algorithmic_bytes / max(info.n_rows, 1),
                 "stream_bytes_per_launch": info.stream_bytes,
-                "streamed_gbs": info.stream_bytes / (k_ms * 1e-3) / 1e9 if (info.stream_bytes and variant == 5) else None,
-                "avg_kernel_ms": k_ms, "avg_pass_ms": tot_ms_sum / max(n_timed, 1), "launches_timed": n_timed,
+                "streamed_gbs": info.stream_bytes / (k_mean * 1e-3) / 1e9 if (info.stream_bytes and variant == 5) else None,
+                "avg_kernel_ms": k_mean, "median_kernel_ms": k_med, "min_kernel_ms": k_min,
+                "avg_pass_ms": p_mean, "median_pass_ms": p_med, "min_pass_ms": p_min, "launches_timed": n_timed,
+                "host_enqueue_ms_per_step": t_enqueued * 1e3 / args.steps,
             },
             "result": {"rare_event": result.rare_event, "mcub": result.mcub, "n_kept": result.n_kept,
                        "argmax_row": result.argmax_row},
-            "model_build_s": t_build, "model_prepare_s": t_prepare,
+            "model_build_s": t_build, "model_prepare_s": t_prepare, "device_bytes": info.device_bytes,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if also is not None:
+            line["also"] = also
+        if world == 1 and not args.no_cpu_baseline and not args.force_dist:
             line["cpu_baseline"] = cpu_baseline(ctx, canopy_amd, args.events, args.avg_nnz, p, args.cpu_sample_rows)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     model.close()
+    if comm is not None:
+        comm.close()
     if comb is not None:
         comb.detach()
     ctx.close()
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -5,8 +5,8 @@ the ctypes binding (_capi), the host-side mirror of the ABI (quantifier) and the
 multi-GPU combine (distributed). PyTorch is used for torch.distributed (RCCL) plumbing only.
 """
 from . import _capi
-from .quantifier import (Context, Model, QuantResult, combine_partials, default_params, importance_measures, shard_rows,
-                         synthetic_probabilities)
+from .quantifier import (Comm, Context, Model, QuantResult, combine_partials, default_params, importance_measures, shard_rows,
+                         synthetic_probabilities, synthetic_shard_bounds)
 
-__all__ = ["Context", "Model", "QuantResult", "combine_partials", "default_params", "importance_measures", "shard_rows",
+__all__ = ["Comm", "synthetic_shard_bounds", "Context", "Model", "QuantResult", "combine_partials", "default_params", "importance_measures", "shard_rows",
            "synthetic_probabilities", "_capi"]

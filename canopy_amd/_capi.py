@@ -21,6 +21,8 @@ ERR_NO_DEVICE = -4
 ERR_UNSUPPORTED = -5
 ERR_INVALID_MODEL = -6
 ERR_STATE = -7
+ERR_INTERNAL = -8
+ERR_RCCL = -9
 
 UPLOAD_VALIDATE = 1
 UPLOAD_DEVICE_POINTERS = 2
@@ -82,6 +84,10 @@ class FtInfo(C.Structure):
                 ("top_gate", C.c_int32), ("n_dag_args", C.c_int32), ("reserved", C.c_int32)]
 
 
+class CommId(C.Structure):
+    _fields_ = [("bytes", C.c_char * 128)]
+
+
 class QuantResult(C.Structure):
     _fields_ = [("rare_event", C.c_double), ("mcub", C.c_double), ("n_kept", C.c_int64),
                 ("argmax_row", C.c_int64), ("max_logp", C.c_double), ("elapsed_kernel_ms", C.c_double)]
@@ -109,6 +115,16 @@ SIGNATURES = {
     "canopy_quantify": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QuantParams), C.POINTER(QuantResult)]),
     "canopy_ctx_partials_device": (C.c_void_p, [C.c_void_p]),
     "canopy_ctx_set_gather_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "canopy_comm_get_unique_id": (C.c_int, [C.POINTER(CommId)]),
+    "canopy_comm_init_rank": (C.c_int, [C.c_void_p, C.POINTER(CommId), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "canopy_comm_init_all": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
+    "canopy_comm_free": (None, [C.c_void_p]),
+    "canopy_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "canopy_comm_quantify_all_async": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
+                                                 C.POINTER(QuantParams)]),
+    "canopy_comm_fetch": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(QuantResult), C.POINTER(Partial)]),
+    "canopy_comm_mc_fetch": (C.c_int, [C.c_void_p, C.POINTER(McResult)]),
+    "canopy_synthetic_shard_bounds": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "canopy_combine_partials": (C.c_int, [C.POINTER(Partial), C.c_int32, C.c_uint32, C.POINTER(QuantResult)]),
     "canopy_fetch_row_logp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "canopy_fetch_keep_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
@@ -143,6 +159,8 @@ SIGNATURES = {
     "canopy_timing_begin": (C.c_int, [C.c_void_p, C.c_int32]),
     "canopy_timing_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int32)]),
+    "canopy_timing_get": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "canopy_last_filter_candidates": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "canopy_synthetic_probabilities": (C.c_int, [C.c_uint64, C.c_int32, C.c_void_p]),
     "canopy_shard_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
 }

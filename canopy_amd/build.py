@@ -13,8 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcanopy.so")
 
 SOURCES = ["canopy_api.hip", "kernels_rows.hip", "kernels_build.hip", "kernels_ws.hip", "kernels_vs.hip", "kernels_mc.hip", "kernels_fr.hip",
-           "kernels_batch.hip", "mef_lowering.cpp"]
-HEADERS = ["canopy_device.h", "canopy_internal.h"]
+           "kernels_batch.hip", "comm_rccl.hip", "mef_lowering.cpp"]
+HEADERS = ["canopy_device.h", "canopy_internal.h", "canopy_guard.h"]
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -58,7 +58,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     if force or jobs or _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", LIB]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-ldl", "-o", LIB]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

@@ -1,7 +1,7 @@
 // canopy_api.hip -- the C ABI of include/canopy.h over the gfx950 kernels.
-// Host code only; every entry point catches its own failures and returns a canopy_status
-// (the reference's error style is C++ exceptions, src/mef/openpsa/error.h:23-96, which cannot
-// cross a C boundary). There is deliberately NO CPU fallback anywhere in this file.
+// Host code only; every entry point returns a canopy_status and is a function-try-block closed by
+// CANOPY_CATCH_ALL (canopy_guard.h): the reference's error style is C++ exceptions,
+// src/mef/openpsa/error.h:23-96, which cannot cross a C boundary. There is deliberately NO CPU fallback anywhere in this file.
 #include <math.h>
 #include <string.h>
 
@@ -51,6 +51,7 @@ canopy_status ensure_block_partials(canopy_ctx* ctx, int grid) {
     ctx->block_partials_cap = 0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_block_partials, sizeof(double) * kAccDoubles * (size_t)grid));
     ctx->block_partials_cap = grid;
+    ++ctx->scratch_gen; // captured passes hold the old pointer
     return CANOPY_OK;
 }
 
@@ -87,6 +88,8 @@ const char* canopy_status_string(canopy_status s) {
         case CANOPY_ERR_UNSUPPORTED: return "unsupported";
         case CANOPY_ERR_INVALID_MODEL: return "invalid CSR model";
         case CANOPY_ERR_STATE: return "invalid call order";
+        case CANOPY_ERR_INTERNAL: return "internal error";
+        case CANOPY_ERR_RCCL: return "RCCL error";
     }
     return "unknown status";
 }
@@ -108,7 +111,7 @@ void canopy_quant_params_default(canopy_quant_params* p) {
 
 // ---- context -----------------------------------------------------------------------------------
 
-canopy_status canopy_ctx_create(const canopy_ctx_params* params, canopy_ctx** out) {
+canopy_status canopy_ctx_create(const canopy_ctx_params* params, canopy_ctx** out) try {
     if (!out) return CANOPY_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     int n_dev = 0;
@@ -150,7 +153,7 @@ canopy_status canopy_ctx_create(const canopy_ctx_params* params, canopy_ctx** ou
     }
     *out = ctx;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 void canopy_ctx_free(canopy_ctx* ctx) {
     if (!ctx) return;
@@ -178,31 +181,32 @@ void canopy_ctx_free(canopy_ctx* ctx) {
 
 const char* canopy_last_error(const canopy_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
-canopy_status canopy_ctx_synchronize(canopy_ctx* ctx) {
+canopy_status canopy_ctx_synchronize(canopy_ctx* ctx) try {
     if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 void* canopy_ctx_partials_device(canopy_ctx* ctx) { return ctx ? ctx->d_partial : nullptr; }
 
 int32_t canopy_last_kernel_variant(const canopy_ctx* ctx) { return ctx ? ctx->last_variant : 0; }
 
-canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* device_buffer, int32_t world_size, int32_t rank) {
+canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* device_buffer, int32_t world_size, int32_t rank) try {
     if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
     if (device_buffer && (world_size < 1 || rank < 0 || rank >= world_size))
         return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "gather buffer: need 0 <= rank < world_size");
+    if (ctx->d_gather != static_cast<double*>(device_buffer)) ++ctx->scratch_gen;
     ctx->d_gather = static_cast<double*>(device_buffer);
     ctx->gather_world = device_buffer ? world_size : 0;
     ctx->gather_rank = device_buffer ? rank : 0;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 // ---- model -------------------------------------------------------------------------------------
 
 canopy_status canopy_model_upload(canopy_ctx* ctx, const canopy_csr_view* csr, uint32_t flags,
-                                  canopy_model** out) {
+                                  canopy_model** out) try {
     if (!ctx || !csr || !out) return CANOPY_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (csr->n_rows < 0 || csr->n_events < 0 || !csr->row_ptr) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "bad csr view");
@@ -276,10 +280,10 @@ canopy_status canopy_model_upload(canopy_ctx* ctx, const canopy_csr_view* csr, u
                                 sizeof(double) * (size_t)m->n_events);
     *out = m;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 canopy_status canopy_model_synthetic(canopy_ctx* ctx, uint64_t seed, int64_t first_row, int64_t n_rows,
-                                     int32_t n_events, int32_t avg_nnz, canopy_model** out) {
+                                     int32_t n_events, int32_t avg_nnz, canopy_model** out) try {
     if (!ctx || !out) return CANOPY_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (n_rows < 0 || first_row < 0 || avg_nnz < 2 || avg_nnz > 17 || n_events < 2 * avg_nnz - 2)
@@ -305,7 +309,7 @@ canopy_status canopy_model_synthetic(canopy_ctx* ctx, uint64_t seed, int64_t fir
                                 sizeof(double) * (size_t)n_events);
     *out = m;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 void canopy_model_free(canopy_model* m) {
     if (!m) return;
@@ -314,7 +318,7 @@ void canopy_model_free(canopy_model* m) {
     delete m;
 }
 
-canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* info) {
+canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* info) try {
     if (!m || !info) return CANOPY_ERR_INVALID_ARGUMENT;
     info->n_rows = m->n_rows; info->nnz = m->nnz; info->row_offset = m->row_offset;
     info->n_events = m->n_events; info->max_row_len = m->max_row_len;
@@ -329,18 +333,18 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
         info->stream_bytes = m->ws_total_chunks * 1024 + (m->n_ws + 1) * 8 + (int64_t)m->n_events * 8;
     info->algorithmic_bytes = (m->n_rows + 1) * 8 + m->nnz * 4 + (int64_t)m->n_events * 8;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_model_download(canopy_ctx* ctx, const canopy_model* m, int64_t* row_ptr, int32_t* col_idx) {
+canopy_status canopy_model_download(canopy_ctx* ctx, const canopy_model* m, int64_t* row_ptr, int32_t* col_idx) try {
     if (!ctx || !m) return CANOPY_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (row_ptr) HIP_TRY(ctx, hipMemcpyAsync(row_ptr, m->d_row_ptr, sizeof(int64_t) * (size_t)(m->n_rows + 1), hipMemcpyDeviceToHost, ctx->stream));
     if (col_idx && m->nnz > 0) HIP_TRY(ctx, hipMemcpyAsync(col_idx, m->d_col_idx, sizeof(int32_t) * (size_t)m->nnz, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_model_set_probabilities(canopy_ctx* ctx, canopy_model* m, const double* p) {
+canopy_status canopy_model_set_probabilities(canopy_ctx* ctx, canopy_model* m, const double* p) try {
     if (!ctx || !m || (!p && m->n_events > 0)) return CANOPY_ERR_INVALID_ARGUMENT;
     for (int32_t j = 0; j < m->n_events; ++j)
         if (!(p[j] >= 0.0 && p[j] <= 1.0))
@@ -354,7 +358,7 @@ canopy_status canopy_model_set_probabilities(canopy_ctx* ctx, canopy_model* m, c
     m->has_p = true;
     ++m->logp_version; // derived tables (the quantised filter table) are stale now
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 // ---- derived layouts -----------------------------------------------------------------------------
 
@@ -404,15 +408,18 @@ canopy_status build_ws(canopy_ctx* ctx, canopy_model* m) {
 
 } // namespace
 
-extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, int32_t kernel) {
+extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, int32_t kernel) try {
     if (!ctx || !m) return CANOPY_ERR_INVALID_ARGUMENT;
     if (m->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "model lives on another device");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int variant = kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : kernel;
     if (kernel == CANOPY_KERNEL_AUTO && m->n_events >= 1 && m->n_events <= fr_max_events() &&
         m->n_rows >= (variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)8000000 : (int64_t)1000000)) {
-        canopy_status fst = build_fr(ctx, m); // AUTO may pick filter/refine for cut_off > 0
+        canopy_status fst = build_fr(ctx, m); // AUTO picks filter/refine for cut_off > 0
         if (fst != CANOPY_OK) return fst;
+        // the stream of the exact all-rows kernel (cut_off = 0, per-row output, > 20 % survivors) is built by the
+        // first pass that needs it: 0.12 s and 2.45 GB at 1e8 rows that a filter/refine workload never reads
+        if (m->fr_state == 1) return CANOPY_OK;
     }
     if (variant == CANOPY_KERNEL_ROWS || variant == CANOPY_KERNEL_ROWS_LDS) return CANOPY_OK;
     if (variant == CANOPY_KERNEL_FILTER_REFINE) {
@@ -435,11 +442,11 @@ extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, 
     if (m->ws_state != 1 && kernel == CANOPY_KERNEL_WAVE_STREAM)
         return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a wave-slab stream");
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 // ---- quantification ----------------------------------------------------------------------------
 
-canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, const canopy_quant_params* params) {
+canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, const canopy_quant_params* params) try {
     if (!ctx || !m) return CANOPY_ERR_INVALID_ARGUMENT;
     if (m->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "model lives on another device");
     if (!m->has_p) return fail(ctx, CANOPY_ERR_STATE, "canopy_model_set_probabilities has not been called");
@@ -505,20 +512,20 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         if (ctx->d_importance) (void)hipFree(ctx->d_importance);
         ctx->d_importance = nullptr; ctx->importance_cap = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_importance, sizeof(double) * (size_t)(m->n_events > 0 ? m->n_events : 1)));
-        ctx->importance_cap = m->n_events;
+        ctx->importance_cap = m->n_events; ++ctx->scratch_gen;
     }
     if (want_rows && ctx->row_logp_cap < m->n_rows) {
         if (ctx->d_row_logp) (void)hipFree(ctx->d_row_logp);
         ctx->d_row_logp = nullptr; ctx->row_logp_cap = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_row_logp, sizeof(double) * (size_t)(m->n_rows > 0 ? m->n_rows : 1)));
-        ctx->row_logp_cap = m->n_rows;
+        ctx->row_logp_cap = m->n_rows; ++ctx->scratch_gen;
     }
     const int64_t n_words = (m->n_rows + 63) / 64;
     if (want_mask && ctx->keep_mask_cap < n_words) {
         if (ctx->d_keep_mask) (void)hipFree(ctx->d_keep_mask);
         ctx->d_keep_mask = nullptr; ctx->keep_mask_cap = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_keep_mask, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1)));
-        ctx->keep_mask_cap = n_words;
+        ctx->keep_mask_cap = n_words; ++ctx->scratch_gen;
     }
 
     int grid;
@@ -573,13 +580,13 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             if (ctx->d_fr_list) (void)hipFree(ctx->d_fr_list);
             ctx->d_fr_list = nullptr; ctx->fr_list_cap = 0;
             HIP_TRY(ctx, hipMalloc(&ctx->d_fr_list, sizeof(uint16_t) * (size_t)(list_len > 0 ? list_len : 1)));
-            ctx->fr_list_cap = list_len;
+            ctx->fr_list_cap = list_len; ++ctx->scratch_gen;
         }
         if (ctx->fr_cnt_cap < m->n_fr_slabs || !ctx->d_fr_cnt) {
             if (ctx->d_fr_cnt) (void)hipFree(ctx->d_fr_cnt);
             ctx->d_fr_cnt = nullptr; ctx->fr_cnt_cap = 0;
             HIP_TRY(ctx, hipMalloc(&ctx->d_fr_cnt, sizeof(unsigned) * (size_t)(m->n_fr_slabs > 0 ? m->n_fr_slabs : 1)));
-            ctx->fr_cnt_cap = m->n_fr_slabs;
+            ctx->fr_cnt_cap = m->n_fr_slabs; ++ctx->scratch_gen;
         }
         if (want_mask) // the refine pass ORs the exact keep bits into a cleared mask
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
@@ -614,6 +621,10 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     HIP_TRY(ctx, launch_finalize(ctx->d_block_partials, n_records, ctx->d_partial, ctx->d_gather, ctx->gather_world,
                                  ctx->gather_rank, variant == CANOPY_KERNEL_FILTER_REFINE ? ctx->d_fr_count : nullptr, ctx->stream));
     ctx->last_variant = variant;
+    if (ctx->comm) { // K5: the one collective of the path, same stream, issued here (not by the host language)
+        canopy_status cst = comm_all_reduce_partials(ctx);
+        if (cst != CANOPY_OK) return cst;
+    }
     if (!ctx->capturing) HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     if (want_imp) { // after the timed pass: one walk over the kept rows
         double* dst = ctx->ext_importance ? ctx->ext_importance : ctx->d_importance;
@@ -625,9 +636,9 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     ctx->last_has_row_logp = want_rows;
     ctx->last_has_mask = (params->flags & CANOPY_QUANT_KEEP_MASK) != 0;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* out) {
+canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* out) try {
     if (!ctx || !out) return CANOPY_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, ctx->d_partial, sizeof(double) * CANOPY_PARTIAL_DOUBLES,
@@ -642,12 +653,14 @@ canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* out) {
         ctx->fr_known_cut_off = ctx->fr_pending_cut_off;
         ctx->fr_known_version = ctx->fr_pending_version;
         ctx->fr_known_fraction = ctx->fr_pending_rows > 0 ? (double)*ctx->h_fr_count / (double)ctx->fr_pending_rows : 0.0;
+        ctx->fr_known_count = (int64_t)*ctx->h_fr_count;
+        ctx->fr_known_rows = ctx->fr_pending_rows;
         ctx->fr_pending_id = 0;
     }
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_combine_partials(const canopy_partial* parts, int32_t n, uint32_t flags, canopy_quant_result* r) {
+canopy_status canopy_combine_partials(const canopy_partial* parts, int32_t n, uint32_t flags, canopy_quant_result* r) try {
     if (!parts || n < 0 || !r) return CANOPY_ERR_INVALID_ARGUMENT;
     CSumH rare, l1p;
     double n_kept = 0.0, n_certain = 0.0, max_logp = -INFINITY, argmax = -1.0;
@@ -670,9 +683,9 @@ canopy_status canopy_combine_partials(const canopy_partial* parts, int32_t n, ui
     r->max_logp = max_logp;
     r->elapsed_kernel_ms = -1.0;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_last_kernel_ms(canopy_ctx* ctx, double* row_kernel_ms, double* total_ms) {
+canopy_status canopy_last_kernel_ms(canopy_ctx* ctx, double* row_kernel_ms, double* total_ms) try {
     if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
     if (!ctx->last_timed) return fail(ctx, CANOPY_ERR_STATE, "no timed launch");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -683,10 +696,10 @@ canopy_status canopy_last_kernel_ms(canopy_ctx* ctx, double* row_kernel_ms, doub
     if (row_kernel_ms) *row_kernel_ms = a;
     if (total_ms) *total_ms = b;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 canopy_status canopy_quantify(canopy_ctx* ctx, const canopy_model* m, const canopy_quant_params* params,
-                              canopy_quant_result* result) {
+                              canopy_quant_result* result) try {
     if (!result) return CANOPY_ERR_INVALID_ARGUMENT;
     const bool was_timing = ctx ? ctx->timing_on : false;
     if (ctx) ctx->timing_on = false; // the synchronous call times itself with ev_last
@@ -696,23 +709,26 @@ canopy_status canopy_quantify(canopy_ctx* ctx, const canopy_model* m, const cano
     canopy_partial part;
     st = canopy_quantify_fetch(ctx, &part);
     if (st != CANOPY_OK) return st;
-    st = canopy_combine_partials(&part, 1, params ? params->flags : 0, result);
+    if (ctx->comm && !ctx->comm->deferred) // every rank ran the collective: the combined result, identical on all ranks
+        st = canopy_comm_fetch(ctx->comm, params ? params->flags : 0, result, nullptr);
+    else
+        st = canopy_combine_partials(&part, 1, params ? params->flags : 0, result);
     if (st != CANOPY_OK) return st;
     double k = -1.0, t = -1.0;
     if (canopy_last_kernel_ms(ctx, &k, &t) == CANOPY_OK) result->elapsed_kernel_ms = t;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_fetch_row_logp(canopy_ctx* ctx, const canopy_model* m, int64_t first_row, int64_t n, double* out) {
+canopy_status canopy_fetch_row_logp(canopy_ctx* ctx, const canopy_model* m, int64_t first_row, int64_t n, double* out) try {
     if (!ctx || !m || !out || first_row < 0 || n < 0 || first_row + n > m->n_rows) return CANOPY_ERR_INVALID_ARGUMENT;
     if (!ctx->last_has_row_logp) return fail(ctx, CANOPY_ERR_STATE, "last pass did not request CANOPY_QUANT_ROW_LOGP");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_row_logp + first_row, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_fetch_keep_mask(canopy_ctx* ctx, const canopy_model* m, int64_t first_word, int64_t n_words, uint64_t* out) {
+canopy_status canopy_fetch_keep_mask(canopy_ctx* ctx, const canopy_model* m, int64_t first_word, int64_t n_words, uint64_t* out) try {
     if (!ctx || !m || !out || first_word < 0 || n_words < 0 || first_word + n_words > (m->n_rows + 63) / 64)
         return CANOPY_ERR_INVALID_ARGUMENT;
     if (!ctx->last_has_mask) return fail(ctx, CANOPY_ERR_STATE, "last pass did not request CANOPY_QUANT_KEEP_MASK");
@@ -720,9 +736,9 @@ canopy_status canopy_fetch_keep_mask(canopy_ctx* ctx, const canopy_model* m, int
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_keep_mask + first_word, sizeof(uint64_t) * (size_t)n_words, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_fetch_importance(canopy_ctx* ctx, const canopy_model* m, double* contrib) {
+canopy_status canopy_fetch_importance(canopy_ctx* ctx, const canopy_model* m, double* contrib) try {
     if (!ctx || !m || (!contrib && m->n_events > 0)) return CANOPY_ERR_INVALID_ARGUMENT;
     if (!ctx->last_has_importance) return fail(ctx, CANOPY_ERR_STATE, "last pass did not request CANOPY_QUANT_IMPORTANCE");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -731,20 +747,22 @@ canopy_status canopy_fetch_importance(canopy_ctx* ctx, const canopy_model* m, do
         HIP_TRY(ctx, hipMemcpyAsync(contrib, src, sizeof(double) * (size_t)m->n_events, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_ctx_set_importance_buffer(canopy_ctx* ctx, void* device_buffer, int32_t n_events) {
+canopy_status canopy_ctx_set_importance_buffer(canopy_ctx* ctx, void* device_buffer, int32_t n_events) try {
     if (!ctx || (device_buffer && n_events < 0)) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (ctx->ext_importance != static_cast<double*>(device_buffer)) ++ctx->scratch_gen;
     ctx->ext_importance = static_cast<double*>(device_buffer);
     ctx->ext_importance_n = device_buffer ? n_events : 0;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 // ---- captured passes ----------------------------------------------------------------------------------------
 
-canopy_status canopy_graph_capture(canopy_ctx* ctx, const canopy_model* m, const canopy_quant_params* params, canopy_graph** out) {
+canopy_status canopy_graph_capture(canopy_ctx* ctx, const canopy_model* m, const canopy_quant_params* params, canopy_graph** out) try {
     if (!ctx || !m || !out) return CANOPY_ERR_INVALID_ARGUMENT;
     *out = nullptr;
+    if (ctx->comm) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "captured passes do not carry the cross-GPU collective: detach the communicator");
     // one ordinary pass first: lazy layouts, scratch buffers and AUTO's choice are settled outside the capture
     canopy_status st = canopy_quantify_async(ctx, m, params);
     if (st != CANOPY_OK) return st;
@@ -766,22 +784,30 @@ canopy_status canopy_graph_capture(canopy_ctx* ctx, const canopy_model* m, const
         return st != CANOPY_OK ? st : fail(ctx, CANOPY_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(e));
     }
     g->variant = ctx->last_variant;
+    g->scratch_gen = ctx->scratch_gen; // the launches hold raw pointers to the context's scratch as it is now
+    g->model = const_cast<canopy_model*>(m);
     g->has_row_logp = ctx->last_has_row_logp; g->has_mask = ctx->last_has_mask; g->has_importance = ctx->last_has_importance;
     *out = g;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_graph_launch(canopy_ctx* ctx, canopy_graph* g) {
+canopy_status canopy_graph_launch(canopy_ctx* ctx, canopy_graph* g) try {
     if (!ctx || !g || !g->exec) return CANOPY_ERR_INVALID_ARGUMENT;
     if (g->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "graph was captured on another device");
+    if (g->scratch_gen != ctx->scratch_gen)
+        return fail(ctx, CANOPY_ERR_STATE,
+                    "the context's scratch or output buffers were reallocated or re-pointed after this graph was captured "
+                    "(a pass over a larger model, a first use of a per-row output, a new gather / importance buffer): capture again");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipGraphLaunch(g->exec, ctx->stream));
+    // a captured FILTER_REFINE pass rewrites the model's quantised table with ITS cut-off: the eager cache key is void
+    if (g->variant == CANOPY_KERNEL_FILTER_REFINE && g->model) g->model->q8_version = 0;
     ctx->last_variant = g->variant;
     ctx->last_has_row_logp = g->has_row_logp; ctx->last_has_mask = g->has_mask; ctx->last_has_importance = g->has_importance;
     ctx->last_timed = false;
     ctx->fr_pending_id = 0; // the candidate-count feedback belongs to eager passes
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 void canopy_graph_free(canopy_graph* g) {
     if (!g) return;
@@ -793,7 +819,7 @@ void canopy_graph_free(canopy_graph* g) {
 
 // ---- timing region -----------------------------------------------------------------------------
 
-canopy_status canopy_timing_begin(canopy_ctx* ctx, int32_t max_launches) {
+canopy_status canopy_timing_begin(canopy_ctx* ctx, int32_t max_launches) try {
     if (!ctx || max_launches < 1 || max_launches > (1 << 20)) return CANOPY_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     while ((int)ctx->ev_pool.size() < max_launches * 3) {
@@ -805,9 +831,9 @@ canopy_status canopy_timing_begin(canopy_ctx* ctx, int32_t max_launches) {
     ctx->timing_n = 0;
     ctx->timing_on = true;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_timing_end(canopy_ctx* ctx, double* row_kernel_ms_sum, double* total_ms_sum, int32_t* n_launches) {
+canopy_status canopy_timing_end(canopy_ctx* ctx, double* row_kernel_ms_sum, double* total_ms_sum, int32_t* n_launches) try {
     if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
     if (!ctx->timing_on) return fail(ctx, CANOPY_ERR_STATE, "timing region not open");
     ctx->timing_on = false;
@@ -824,11 +850,30 @@ canopy_status canopy_timing_end(canopy_ctx* ctx, double* row_kernel_ms_sum, doub
     if (total_ms_sum) *total_ms_sum = ts;
     if (n_launches) *n_launches = ctx->timing_n;
     return CANOPY_OK;
+} CANOPY_CATCH_ALL
+
+canopy_status canopy_timing_get(canopy_ctx* ctx, int32_t i, double* row_kernel_ms, double* total_ms) try {
+    if (!ctx || i < 0 || i >= ctx->timing_n) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (ctx->timing_on) return fail(ctx, CANOPY_ERR_STATE, "timing region still open");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev_pool[(size_t)i * 3], ctx->ev_pool[(size_t)i * 3 + 1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev_pool[(size_t)i * 3], ctx->ev_pool[(size_t)i * 3 + 2]));
+    if (row_kernel_ms) *row_kernel_ms = a;
+    if (total_ms) *total_ms = b;
+    return CANOPY_OK;
+} CANOPY_CATCH_ALL
+
+canopy_status canopy_last_filter_candidates(const canopy_ctx* ctx, int64_t* n_candidates, int64_t* n_rows) {
+    if (!ctx || ctx->fr_known_id == 0) return CANOPY_ERR_STATE;
+    if (n_candidates) *n_candidates = ctx->fr_known_count;
+    if (n_rows) *n_rows = ctx->fr_known_rows;
+    return CANOPY_OK;
 }
 
 // ---- host logic --------------------------------------------------------------------------------
 
-canopy_status canopy_synthetic_probabilities(uint64_t seed, int32_t n_events, double* p) {
+canopy_status canopy_synthetic_probabilities(uint64_t seed, int32_t n_events, double* p) try {
     if (n_events < 0 || (!p && n_events > 0)) return CANOPY_ERR_INVALID_ARGUMENT;
     const uint64_t key = stream_key(seed, kStreamProb);
     for (int32_t j = 0; j < n_events; ++j) {
@@ -836,9 +881,37 @@ canopy_status canopy_synthetic_probabilities(uint64_t seed, int32_t n_events, do
         p[j] = pow(10.0, -8.0 + 5.0 * u);
     }
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_shard_rows(const int64_t* row_ptr, int64_t n_rows, int32_t n_shards, int64_t* bounds) {
+canopy_status canopy_synthetic_shard_bounds(canopy_ctx* ctx, uint64_t seed, int64_t n_rows, int32_t avg_nnz,
+                                            int32_t n_shards, int64_t* bounds) try {
+    if (!ctx || !bounds || n_rows < 0 || n_shards < 1 || avg_nnz < 2 || avg_nnz > 17) return CANOPY_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int64_t* d_rp = nullptr;
+    HIP_TRY(ctx, synth_row_ptr(seed, 0, n_rows, avg_nnz, &d_rp, ctx->stream)); // lengths + scan only: no columns
+    auto at = [&](int64_t r, int64_t* v) { return hipMemcpy(v, d_rp + r, sizeof(int64_t), hipMemcpyDeviceToHost); };
+    int64_t nnz = 0;
+    hipError_t e = at(n_rows, &nnz);
+    bounds[0] = 0;
+    for (int32_t k = 1; k < n_shards && e == hipSuccess; ++k) { // the rule of canopy_shard_rows, searched on the device array
+        if (nnz == 0) { bounds[k] = n_rows * k / n_shards; continue; }
+        const int64_t target = (int64_t)(((__int128)nnz * k) / n_shards);
+        int64_t lo = 0, hi = n_rows; // first r with row_ptr[r] >= target
+        while (lo < hi && e == hipSuccess) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            int64_t v = 0;
+            e = at(mid, &v);
+            if (v >= target) hi = mid; else lo = mid + 1;
+        }
+        bounds[k] = lo < bounds[k - 1] ? bounds[k - 1] : lo;
+    }
+    bounds[n_shards] = n_rows;
+    (void)hipFree(d_rp);
+    HIP_TRY(ctx, e);
+    return CANOPY_OK;
+} CANOPY_CATCH_ALL
+
+canopy_status canopy_shard_rows(const int64_t* row_ptr, int64_t n_rows, int32_t n_shards, int64_t* bounds) try {
     if (!row_ptr || !bounds || n_rows < 0 || n_shards < 1) return CANOPY_ERR_INVALID_ARGUMENT;
     const int64_t base = row_ptr[0], nnz = row_ptr[n_rows] - base;
     if (nnz < 0) return CANOPY_ERR_INVALID_MODEL;
@@ -855,6 +928,6 @@ canopy_status canopy_shard_rows(const int64_t* row_ptr, int64_t n_rows, int32_t 
     }
     bounds[n_shards] = n_rows;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 } // extern "C"

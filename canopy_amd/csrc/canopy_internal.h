@@ -8,14 +8,18 @@
 #include <vector>
 
 #include "canopy.h"
+#include "canopy_guard.h"
 
 namespace canopy {
 struct BatchState; // kernels_batch.hip
 void batch_state_free(BatchState* b);
 } // namespace canopy
 
+struct canopy_comm;
+
 struct canopy_ctx {
     int device = 0;
+    canopy_comm* comm = nullptr; // K5 inside the library (comm_rccl.hip); owned by the caller, detached by canopy_comm_free
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int n_cu = 0;
@@ -57,6 +61,7 @@ struct canopy_ctx {
     int64_t fr_pending_rows = 0;
     uint64_t fr_known_id = 0;     // last model id with a known candidate fraction
     double fr_known_fraction = -1.0;
+    int64_t fr_known_count = 0, fr_known_rows = 0;
     double fr_known_cut_off = -1.0, fr_pending_cut_off = -1.0; // the feedback applies to the same (model, p, cut-off) only
     uint64_t fr_known_version = 0, fr_pending_version = 0;
     // K6 Monte-Carlo
@@ -67,9 +72,22 @@ struct canopy_ctx {
     // batched quantification (lazily created)
     canopy::BatchState* batch = nullptr;
 
+    uint64_t scratch_gen = 0; // bumped whenever a scratch / output buffer a captured pass may point at is replaced
     bool capturing = false; // inside canopy_graph_capture: no timing events, derived tables always rebuilt
 
     std::string last_error;
+};
+
+struct canopy_comm {
+    canopy_ctx* ctx = nullptr;
+    void* comm = nullptr;   // ncclComm_t
+    int world = 1, rank = 0;
+    double* d_buf = nullptr; // [world][8] gather slots = the all-reduce buffer
+    double* h_buf = nullptr; // pinned mirror
+    unsigned long long* d_mc = nullptr; // [2] {hits, trials} of the Monte-Carlo combine
+    unsigned long long* h_mc = nullptr;
+    bool mc_valid = false;
+    bool deferred = false;   // one process, N devices: the collectives of a pass are issued together, grouped
 };
 
 struct canopy_graph {
@@ -77,6 +95,8 @@ struct canopy_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t model_id = 0;
+    canopy_model* model = nullptr; // must outlive the graph (canopy.h)
+    uint64_t scratch_gen = 0;      // canopy_ctx::scratch_gen at capture
     int32_t variant = 0;
     bool has_row_logp = false, has_mask = false, has_importance = false;
 };
@@ -156,10 +176,16 @@ hipError_t launch_validate_csr(const int64_t* row_ptr, const int32_t* col_idx, i
                                hipStream_t s);
 hipError_t launch_rebase_row_ptr(int64_t* row_ptr, int64_t n_plus_1, int64_t base, hipStream_t s);
 hipError_t scan_inclusive_i64(int64_t* data, int64_t n, hipStream_t s);
+hipError_t synth_row_ptr(uint64_t seed, int64_t first_row, int64_t n_rows, int32_t avg_nnz, int64_t** d_row_ptr_out,
+                         hipStream_t s);
 hipError_t synth_build_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int32_t n_events,
                            int32_t avg_nnz, int64_t** d_row_ptr_out, int32_t** d_col_idx_out,
                            int64_t* nnz_out, hipStream_t s);
 
+
+// comm_rccl.hip
+canopy_status comm_all_reduce_partials(canopy_ctx* ctx);
+canopy_status comm_all_reduce_mc(canopy_ctx* ctx, const unsigned long long* d_hits, long long trials);
 
 // kernels_ws.hip
 int ws_rows_per_wave();

@@ -307,7 +307,7 @@ void log_rows(const double* p, double* out, int64_t n, bool is_log, int* bad) {
 extern "C" {
 
 canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* m, const double* p_trials, int32_t n_trials,
-                                          const canopy_quant_params* params, uint32_t batch_flags, void* device_out) {
+                                          const canopy_quant_params* params, uint32_t batch_flags, void* device_out) try {
     if (!ctx || !m || !p_trials || n_trials < 1) return CANOPY_ERR_INVALID_ARGUMENT;
     if (m->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "model lives on another device");
     canopy_quant_params prm;
@@ -439,9 +439,9 @@ canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* m, cons
     b->n_candidates = n_c;
     b->nnz_candidates = nnz_c;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_quantify_batch_fetch(canopy_ctx* ctx, canopy_partial* partials, int32_t n_trials, canopy_batch_info* info) {
+canopy_status canopy_quantify_batch_fetch(canopy_ctx* ctx, canopy_partial* partials, int32_t n_trials, canopy_batch_info* info) try {
     if (!ctx || !partials) return CANOPY_ERR_INVALID_ARGUMENT;
     BatchState* b = ctx->batch;
     if (!b || b->n_trials == 0) return fail(ctx, CANOPY_ERR_STATE, "no batch has been enqueued");
@@ -468,11 +468,11 @@ canopy_status canopy_quantify_batch_fetch(canopy_ctx* ctx, canopy_partial* parti
         info->host_log_ms = b->host_log_ms;
     }
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 canopy_status canopy_quantify_batch(canopy_ctx* ctx, canopy_model* m, const double* p_trials, int32_t n_trials,
                                     const canopy_quant_params* params, uint32_t batch_flags, canopy_quant_result* results,
-                                    canopy_batch_info* info) {
+                                    canopy_batch_info* info) try {
     if (!results) return CANOPY_ERR_INVALID_ARGUMENT;
     canopy_status st = canopy_quantify_batch_async(ctx, m, p_trials, n_trials, params, batch_flags, nullptr);
     if (st != CANOPY_OK) return st;
@@ -487,6 +487,6 @@ canopy_status canopy_quantify_batch(canopy_ctx* ctx, canopy_model* m, const doub
     }
     if (info) *info = bi;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 } // extern "C"

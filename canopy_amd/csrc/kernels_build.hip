@@ -190,11 +190,10 @@ hipError_t launch_rebase_row_ptr(int64_t* row_ptr, int64_t n_plus_1, int64_t bas
     return hipGetLastError();
 }
 
-hipError_t synth_build_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int32_t n_events,
-                           int32_t avg_nnz, int64_t** d_row_ptr_out, int32_t** d_col_idx_out,
-                           int64_t* nnz_out, hipStream_t s) {
+// row_ptr (rebased to 0) of rows [first_row, first_row + n_rows) of the synthetic family: lengths + scan.
+hipError_t synth_row_ptr(uint64_t seed, int64_t first_row, int64_t n_rows, int32_t avg_nnz, int64_t** d_row_ptr_out,
+                         hipStream_t s) {
     int64_t* d_row_ptr = nullptr;
-    int32_t* d_col = nullptr;
     hipError_t e = hipMalloc(&d_row_ptr, sizeof(int64_t) * (size_t)(n_rows + 1));
     if (e != hipSuccess) return e;
     const uint32_t span = (uint32_t)(2 * avg_nnz - 3);
@@ -202,6 +201,19 @@ hipError_t synth_build_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int
                        stream_key(seed, kStreamLen), first_row, n_rows, span, d_row_ptr);
     e = hipGetLastError();
     if (e == hipSuccess) e = scan_inclusive(d_row_ptr + 1, n_rows, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(d_row_ptr); return e; }
+    *d_row_ptr_out = d_row_ptr;
+    return hipSuccess;
+}
+
+hipError_t synth_build_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int32_t n_events,
+                           int32_t avg_nnz, int64_t** d_row_ptr_out, int32_t** d_col_idx_out,
+                           int64_t* nnz_out, hipStream_t s) {
+    int64_t* d_row_ptr = nullptr;
+    int32_t* d_col = nullptr;
+    hipError_t e = synth_row_ptr(seed, first_row, n_rows, avg_nnz, &d_row_ptr, s);
+    if (e != hipSuccess) return e;
     int64_t nnz = 0;
     if (e == hipSuccess)
         e = hipMemcpyAsync(&nnz, d_row_ptr + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, s);

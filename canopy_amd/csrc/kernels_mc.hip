@@ -288,7 +288,7 @@ void free_dag(canopy_dag* d) {
 
 extern "C" {
 
-canopy_status canopy_dag_upload(canopy_ctx* ctx, const canopy_dag_view* v, canopy_dag** out) {
+canopy_status canopy_dag_upload(canopy_ctx* ctx, const canopy_dag_view* v, canopy_dag** out) try {
     if (!ctx || !v || !out) return CANOPY_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (v->n_events < 0 || v->n_gates < 0 || (v->n_gates > 0 && (!v->gate_type || !v->arg_ptr)))
@@ -462,11 +462,11 @@ canopy_status canopy_dag_upload(canopy_ctx* ctx, const canopy_dag_view* v, canop
     }
     *out = d;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 void canopy_dag_free(canopy_dag* dag) { free_dag(dag); }
 
-canopy_status canopy_dag_set_probabilities(canopy_ctx* ctx, canopy_dag* d, const double* p) {
+canopy_status canopy_dag_set_probabilities(canopy_ctx* ctx, canopy_dag* d, const double* p) try {
     if (!ctx || !d || (!p && d->n_events > 0)) return CANOPY_ERR_INVALID_ARGUMENT;
     std::vector<uint64_t> t((size_t)d->n_events);
     for (int32_t j = 0; j < d->n_events; ++j) {
@@ -479,9 +479,9 @@ canopy_status canopy_dag_set_probabilities(canopy_ctx* ctx, canopy_dag* d, const
         HIP_TRY(ctx, hipMemcpy(d->d_thresh, t.data(), sizeof(uint64_t) * t.size(), hipMemcpyHostToDevice));
     d->has_p = true;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* d, const canopy_mc_params* prm) {
+canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* d, const canopy_mc_params* prm) try {
     if (!ctx || !d || !prm) return CANOPY_ERR_INVALID_ARGUMENT;
     if (d->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "dag lives on another device");
     if (!d->has_p) return fail(ctx, CANOPY_ERR_STATE, "canopy_dag_set_probabilities has not been called");
@@ -562,12 +562,16 @@ canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* d, const ca
     }
 #undef MC_GO
     HIP_TRY(ctx, hipGetLastError());
+    if (ctx->comm) { // shards of the sample range add: one u64 sum all-reduce of {hits, trials}
+        canopy_status cst = comm_all_reduce_mc(ctx, ctx->d_mc_hits, (long long)prm->num_trials);
+        if (cst != CANOPY_OK) return cst;
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_mc[1], ctx->stream));
     ctx->mc_last_trials = prm->num_trials;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_mc_fetch(canopy_ctx* ctx, canopy_mc_result* r) {
+canopy_status canopy_mc_fetch(canopy_ctx* ctx, canopy_mc_result* r) try {
     if (!ctx || !r) return CANOPY_ERR_INVALID_ARGUMENT;
     if (!ctx->d_mc_hits) return fail(ctx, CANOPY_ERR_STATE, "no Monte-Carlo pass has been enqueued");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -581,13 +585,13 @@ canopy_status canopy_mc_fetch(canopy_ctx* ctx, canopy_mc_result* r) {
     r->std_error = r->num_trials > 0 ? sqrt(r->estimate * (1.0 - r->estimate) / (double)r->num_trials) : 0.0;
     r->elapsed_kernel_ms = ms;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_mc_run(canopy_ctx* ctx, const canopy_dag* d, const canopy_mc_params* prm, canopy_mc_result* r) {
+canopy_status canopy_mc_run(canopy_ctx* ctx, const canopy_dag* d, const canopy_mc_params* prm, canopy_mc_result* r) try {
     if (!r) return CANOPY_ERR_INVALID_ARGUMENT;
     canopy_status st = canopy_mc_run_async(ctx, d, prm);
     if (st != CANOPY_OK) return st;
     return canopy_mc_fetch(ctx, r);
-}
+} CANOPY_CATCH_ALL
 
 } // extern "C"

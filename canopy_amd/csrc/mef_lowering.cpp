@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "canopy.h"
+#include "canopy_guard.h"
 
 namespace {
 
@@ -56,7 +57,12 @@ struct XmlParser {
         if (p == b) fail("name expected");
         return std::string(b, p);
     }
+    static constexpr int kMaxDepth = 256; // untrusted input: the recursion below must not exhaust the stack
+    int depth = 0;
+    struct DepthGuard { int& d; explicit DepthGuard(int& x) : d(x) { ++d; } ~DepthGuard() { --d; } };
     XmlNode element() { // p at '<' of a start tag
+        DepthGuard guard(depth);
+        if (depth > kMaxDepth) fail("elements nested deeper than 256 levels");
         ++p;
         XmlNode n;
         n.name = name_tok();
@@ -416,7 +422,7 @@ void set_err(char* err, size_t n, const std::string& m) {
 
 extern "C" {
 
-canopy_status canopy_ft_parse(const char* xml_text, size_t len, canopy_ft** out, char* err, size_t err_len) {
+canopy_status canopy_ft_parse(const char* xml_text, size_t len, canopy_ft** out, char* err, size_t err_len) try {
     if (!xml_text || !out) return CANOPY_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     canopy_ft* ft = new (std::nothrow) canopy_ft();
@@ -436,9 +442,9 @@ canopy_status canopy_ft_parse(const char* xml_text, size_t len, canopy_ft** out,
     }
     *out = ft;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_ft_parse_file(const char* path, canopy_ft** out, char* err, size_t err_len) {
+canopy_status canopy_ft_parse_file(const char* path, canopy_ft** out, char* err, size_t err_len) try {
     if (!path || !out) return CANOPY_ERR_INVALID_ARGUMENT;
     FILE* f = fopen(path, "rb");
     if (!f) { set_err(err, err_len, std::string("cannot open ") + path); return CANOPY_ERR_INVALID_ARGUMENT; }
@@ -448,11 +454,11 @@ canopy_status canopy_ft_parse_file(const char* path, canopy_ft** out, char* err,
     while ((n = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, n);
     fclose(f);
     return canopy_ft_parse(text.data(), text.size(), out, err, err_len);
-}
+} CANOPY_CATCH_ALL
 
 void canopy_ft_free(canopy_ft* ft) { delete ft; }
 
-canopy_status canopy_ft_get_info(const canopy_ft* ft, canopy_ft_info* info) {
+canopy_status canopy_ft_get_info(const canopy_ft* ft, canopy_ft_info* info) try {
     if (!ft || !info) return CANOPY_ERR_INVALID_ARGUMENT;
     info->n_basic_events = (int32_t)ft->basic_names.size();
     info->n_gates = (int32_t)ft->d_type.size();
@@ -461,7 +467,7 @@ canopy_status canopy_ft_get_info(const canopy_ft* ft, canopy_ft_info* info) {
     info->n_dag_args = (int32_t)ft->d_args.size();
     info->reserved = ft->top_const ? (ft->top_const_value ? 2 : 1) : 0; /* 0 regular, 1 top == false, 2 top == true */
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 const char* canopy_ft_basic_event_name(const canopy_ft* ft, int32_t j) {
     return (ft && j >= 0 && (size_t)j < ft->basic_names.size()) ? ft->basic_names[(size_t)j].c_str() : "";
@@ -470,13 +476,13 @@ const char* canopy_ft_gate_name(const canopy_ft* ft, int32_t g) {
     return (ft && g >= 0 && (size_t)g < ft->gates.size()) ? ft->gates[(size_t)g].name.c_str() : "";
 }
 
-canopy_status canopy_ft_probabilities(const canopy_ft* ft, double* p) {
+canopy_status canopy_ft_probabilities(const canopy_ft* ft, double* p) try {
     if (!ft || (!p && !ft->p.empty())) return CANOPY_ERR_INVALID_ARGUMENT;
     for (size_t j = 0; j < ft->p.size(); ++j) p[j] = ft->p[j];
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_ft_dag(const canopy_ft* ft, int32_t* gate_type, int32_t* gate_min, int32_t* arg_ptr, int32_t* args, int32_t* top) {
+canopy_status canopy_ft_dag(const canopy_ft* ft, int32_t* gate_type, int32_t* gate_min, int32_t* arg_ptr, int32_t* args, int32_t* top) try {
     if (!ft || !arg_ptr || !top) return CANOPY_ERR_INVALID_ARGUMENT;
     if (ft->top_const) return CANOPY_ERR_UNSUPPORTED; // the house events decide the top event: nothing to simulate
     for (size_t g = 0; g < ft->d_type.size(); ++g) { gate_type[g] = ft->d_type[g]; gate_min[g] = ft->d_min[g]; }
@@ -484,9 +490,9 @@ canopy_status canopy_ft_dag(const canopy_ft* ft, int32_t* gate_type, int32_t* ga
     for (size_t k = 0; k < ft->d_args.size(); ++k) args[k] = ft->d_args[k];
     *top = ft->d_top;
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
-canopy_status canopy_ft_cut_sets(const canopy_ft* ft, int32_t limit_order, int64_t* n_sets, int64_t* nnz, int64_t* row_ptr, int32_t* col_idx) {
+canopy_status canopy_ft_cut_sets(const canopy_ft* ft, int32_t limit_order, int64_t* n_sets, int64_t* nnz, int64_t* row_ptr, int32_t* col_idx) try {
     if (!ft || !n_sets || !nnz || limit_order < 0) return CANOPY_ERR_INVALID_ARGUMENT;
     std::vector<CutSet> cs;
     try {
@@ -509,6 +515,6 @@ canopy_status canopy_ft_cut_sets(const canopy_ft* ft, int32_t limit_order, int64
         }
     }
     return CANOPY_OK;
-}
+} CANOPY_CATCH_ALL
 
 } // extern "C"

@@ -21,6 +21,18 @@ from . import _capi as capi
 from .quantifier import combine_partials
 
 
+def library_comm(ctx, group=None):
+    """Bootstrap libcanopy's own RCCL communicator (canopy_comm_init_rank) over an existing torch.distributed
+    group of ANY backend (gloo is enough): rank 0 makes the 128-byte id, one broadcast hands it out. After this the
+    data path needs no Python: canopy_quantify_async itself ends with the all-reduce. -> canopy_amd.Comm"""
+    from .quantifier import Comm
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    box = [Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return Comm(ctx, box[0], world, rank)
+
+
 class ShardCombiner:
     def __init__(self, ctx=None, group=None, device=None):
         self.group = group

@@ -169,6 +169,22 @@ class Context:
         capi.check(capi.lib().canopy_timing_end(self._h, C.byref(a), C.byref(b), C.byref(n)), "canopy_timing_end", self._h)
         return a.value, b.value, n.value
 
+    def timing_launches(self, n):
+        """[(row_kernel_ms, pass_ms)] of the first n launches of the last closed timing region."""
+        out = []
+        a, b = C.c_double(), C.c_double()
+        for i in range(n):
+            capi.check(capi.lib().canopy_timing_get(self._h, i, C.byref(a), C.byref(b)), "canopy_timing_get", self._h)
+            out.append((a.value, b.value))
+        return out
+
+    def last_filter_candidates(self):
+        """(rows flagged by the last fetched FILTER_REFINE pass, rows it looked at) or None."""
+        a, b = C.c_int64(), C.c_int64()
+        if capi.lib().canopy_last_filter_candidates(self._h, C.byref(a), C.byref(b)) != capi.OK:
+            return None
+        return a.value, b.value
+
     def fetch_row_logp(self, model, first_row=0, n=None):
         n = model.info().n_rows - first_row if n is None else n
         out = np.empty(n, dtype=np.float64)
@@ -183,6 +199,64 @@ class Context:
         capi.check(capi.lib().canopy_fetch_keep_mask(self._h, model.handle, first_word, n_words, out.ctypes.data),
                    "canopy_fetch_keep_mask", self._h)
         return out
+
+
+class Comm:
+    """K5 inside the library (canopy_comm): the single RCCL all-reduce is issued by libcanopy.so itself, right
+    behind the final-reduce kernel of every pass on the context. One process per GPU: rank 0 makes the id
+    (Comm.unique_id()), the launcher hands its 128 bytes to every rank, every rank constructs Comm(ctx, id, world,
+    rank) -- a collective call. Free it before its context."""
+
+    def __init__(self, ctx, comm_id, world_size, rank):
+        cid = capi.CommId()
+        C.memmove(C.byref(cid), bytes(comm_id), 128)
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        capi.check(capi.lib().canopy_comm_init_rank(ctx.handle, C.byref(cid), world_size, rank, C.byref(self._h)),
+                   "canopy_comm_init_rank", ctx.handle)
+        self.world, self.rank = world_size, rank
+
+    @staticmethod
+    def unique_id():
+        cid = capi.CommId()
+        capi.check(capi.lib().canopy_comm_get_unique_id(C.byref(cid)), "canopy_comm_get_unique_id")
+        return bytes(bytearray(C.string_at(C.byref(cid), 128)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def rccl_version(self):
+        v = C.c_int32()
+        capi.check(capi.lib().canopy_comm_info(self._h, None, None, C.byref(v)), "canopy_comm_info")
+        return v.value
+
+    def fetch(self, flags=0):
+        """Combined result of the last pass (waits for the stream; identical on every rank)."""
+        res = capi.QuantResult()
+        capi.check(capi.lib().canopy_comm_fetch(self._h, flags, C.byref(res), None), "canopy_comm_fetch", self._ctx.handle)
+        return QuantResult(res.rare_event, res.mcub, res.n_kept, res.argmax_row, res.max_logp, -1.0)
+
+    def partials(self):
+        parts = (capi.Partial * self.world)()
+        capi.check(capi.lib().canopy_comm_fetch(self._h, 0, None, parts), "canopy_comm_fetch", self._ctx.handle)
+        return list(parts)
+
+    def mc_fetch(self):
+        res = capi.McResult()
+        capi.check(capi.lib().canopy_comm_mc_fetch(self._h, C.byref(res)), "canopy_comm_mc_fetch", self._ctx.handle)
+        return res
+
+    def close(self):
+        if self._h:
+            capi.lib().canopy_comm_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Dag:
@@ -315,6 +389,14 @@ def shard_rows(row_ptr, n_shards):
     bounds = np.empty(n_shards + 1, dtype=np.int64)
     capi.check(capi.lib().canopy_shard_rows(row_ptr.ctypes.data, len(row_ptr) - 1, n_shards, bounds.ctypes.data),
                "canopy_shard_rows")
+    return bounds
+
+
+def synthetic_shard_bounds(ctx, seed, n_rows, avg_nnz, n_shards):
+    """nnz-balanced contiguous row ranges of the synthetic family (canopy_shard_rows' rule, evaluated on the device)."""
+    bounds = np.empty(n_shards + 1, dtype=np.int64)
+    capi.check(capi.lib().canopy_synthetic_shard_bounds(ctx.handle, seed, n_rows, avg_nnz, n_shards, bounds.ctypes.data),
+               "canopy_synthetic_shard_bounds", ctx.handle)
     return bounds
 
 

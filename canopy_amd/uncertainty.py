@@ -13,17 +13,20 @@ import numpy as np
 
 from .quantifier import default_params
 
-_Z = {0.90: 1.6448536269514722, 0.95: 1.959963984540054, 0.99: 2.5758293035489004}
+_Z = {0.90: 1.2815515655446004, 0.95: 1.6448536269514722, 0.99: 2.3263478740408408}
 
 
 def _z(level):
-    """two-sided normal quantile z with P(|X| < z) = level (EF = exp(z * sigma), random_deviate.h:109-111)."""
+    """z_alpha of the header's EF = exp(z_alpha * sigma) (random_deviate.h:109-111): the ONE-sided upper normal
+    quantile, P(X < z) = level, as in the Open-PSA / SCRAM lineage -- the error factor is the `level` quantile of the
+    deviate over its median (0.95 -> 1.645). The reference holds no body for this deviate, so the reading is
+    unpinned by the reference."""
     if level in _Z:
         return _Z[level]
-    if not 0.0 < level < 1.0:
-        raise ValueError("confidence level must lie in (0, 1)")
+    if not 0.5 < level < 1.0:
+        raise ValueError("confidence level must lie in (0.5, 1)")
     from statistics import NormalDist
-    return NormalDist().inv_cdf(0.5 + level / 2.0)
+    return NormalDist().inv_cdf(level)
 
 
 def sample_trials(distributions, n_trials, seed=0):

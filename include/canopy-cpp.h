@@ -62,6 +62,8 @@ public:
         return model_ptr(m);
     }
     void set_probabilities(const model_ptr& m, const std::vector<double>& p) const {
+        if (p.size() != (size_t)model_info(m).n_events)
+            throw error(CANOPY_ERR_INVALID_ARGUMENT, "set_probabilities", "p must hold n_events probabilities");
         check(canopy_model_set_probabilities(get(), m.get(), p.data()), "canopy_model_set_probabilities");
     }
     canopy_quant_result quantify(const model_ptr& m, const canopy_quant_params& params = quant_params()) const {
@@ -82,9 +84,16 @@ public:
     std::vector<canopy_quant_result> quantify_batch(const model_ptr& m, const std::vector<double>& p_trials, int32_t n_trials,
                                                     const canopy_quant_params& params = quant_params(),
                                                     canopy_batch_info* info = nullptr) const {
-        std::vector<canopy_quant_result> r((size_t)(n_trials > 0 ? n_trials : 0));
+        if (n_trials < 0 || p_trials.size() != (size_t)n_trials * (size_t)model_info(m).n_events)
+            throw error(CANOPY_ERR_INVALID_ARGUMENT, "quantify_batch", "p_trials must hold n_trials x n_events values");
+        std::vector<canopy_quant_result> r((size_t)n_trials);
         check(canopy_quantify_batch(get(), m.get(), p_trials.data(), n_trials, &params, 0, r.data(), info), "canopy_quantify_batch");
         return r;
+    }
+    canopy_model_info model_info(const model_ptr& m) const {
+        canopy_model_info i;
+        check(canopy_model_get_info(m.get(), &i), "canopy_model_get_info");
+        return i;
     }
     void synchronize() const { check(canopy_ctx_synchronize(get()), "canopy_ctx_synchronize"); }
 

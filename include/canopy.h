@@ -65,7 +65,9 @@ typedef enum canopy_status {
     CANOPY_ERR_UNSUPPORTED = -5,
     CANOPY_ERR_INVALID_MODEL = -6, /* CSR failed validation (row_ptr not monotone, column out of
                                       range, columns not strictly ascending within a row) */
-    CANOPY_ERR_STATE = -7          /* call order violated (e.g. quantify before set_probabilities) */
+    CANOPY_ERR_STATE = -7,         /* call order violated (e.g. quantify before set_probabilities) */
+    CANOPY_ERR_INTERNAL = -8,      /* an unexpected C++ exception was caught at the boundary */
+    CANOPY_ERR_RCCL = -9           /* an RCCL call of the cross-GPU combine failed (canopy_last_error has its text) */
 } canopy_status;
 
 CANOPY_API const char* canopy_status_string(canopy_status s);
@@ -253,9 +255,49 @@ CANOPY_API void* canopy_ctx_partials_device(canopy_ctx* ctx);
 CANOPY_API canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* device_buffer,
                                                       int32_t world_size, int32_t rank);
 
+/*
+ * K5 inside the library: the single RCCL all-reduce of the path, issued by libcanopy itself on the context's
+ * stream right behind the final-reduce kernel -- a C or C++ host (the reference's library target,
+ * src/CMakeLists.txt:9-23) needs nothing else for the multi-GPU path. The library owns the world x 8 slot buffer
+ * (canopy_ctx_set_gather_buffer semantics); librccl.so.1 is bound on first use, so single-GPU hosts need no RCCL.
+ *
+ *   one process per GPU:   rank 0 calls canopy_comm_get_unique_id and hands the 128 bytes to the other ranks by
+ *                          whatever channel the launcher has (MPI, a file, an environment variable, a TCP store);
+ *                          EVERY rank then calls canopy_comm_init_rank (collective). From then on every
+ *                          canopy_quantify_async on that context ends with the all-reduce, canopy_quantify returns
+ *                          the COMBINED result on every rank (so every rank must call it), and
+ *                          canopy_comm_fetch delivers the combined result of an asynchronous pass.
+ *   one process, N GPUs:   canopy_comm_init_all over N contexts (one per device), then
+ *                          canopy_comm_quantify_all_async runs the pass on every device and issues the N collectives
+ *                          inside ncclGroupStart / ncclGroupEnd; canopy_comm_fetch on any of them.
+ * The fold over the world records is done on the host in rank order: bitwise identical on every rank.
+ * Monte-Carlo (K6): with a communicator attached (process-per-GPU shape) canopy_mc_run_async also sums
+ * {hits, trials} over the ranks (one u64 all-reduce); canopy_comm_mc_fetch returns the global estimate.
+ * canopy_comm_free detaches (the context returns to single-shard behaviour); free it before its context.
+ */
+#define CANOPY_COMM_ID_BYTES 128
+typedef struct canopy_comm_id { char bytes[CANOPY_COMM_ID_BYTES]; } canopy_comm_id;
+typedef struct canopy_comm canopy_comm;
+
+CANOPY_API canopy_status canopy_comm_get_unique_id(canopy_comm_id* id);
+CANOPY_API canopy_status canopy_comm_init_rank(canopy_ctx* ctx, const canopy_comm_id* id, int32_t world_size,
+                                               int32_t rank, canopy_comm** out);
+CANOPY_API canopy_status canopy_comm_init_all(canopy_ctx* const* ctxs, int32_t n, canopy_comm** out /* [n] */);
+CANOPY_API void canopy_comm_free(canopy_comm* comm);
+/* Any of the three may be NULL. rccl_version: NCCL-style code of the bound library (e.g. 22707). */
+CANOPY_API canopy_status canopy_comm_info(const canopy_comm* comm, int32_t* world_size, int32_t* rank,
+                                          int32_t* rccl_version);
+CANOPY_API canopy_status canopy_comm_quantify_all_async(canopy_comm* const* comms, const canopy_model* const* models,
+                                                        int32_t n, const canopy_quant_params* params);
+
 /* Host-side, deterministic combine of n shard records in index order. */
 CANOPY_API canopy_status canopy_combine_partials(const canopy_partial* parts, int32_t n,
                                                  uint32_t flags, canopy_quant_result* result);
+
+/* Wait for the context's stream, copy the world records to the host, fold them in rank order. result and/or
+   parts[world_size] may be NULL. flags: CANOPY_QUANT_CLAMP. */
+CANOPY_API canopy_status canopy_comm_fetch(canopy_comm* comm, uint32_t flags, canopy_quant_result* result,
+                                           canopy_partial* parts);
 
 /* Optional per-row outputs of the last pass that requested them (host destination). */
 CANOPY_API canopy_status canopy_fetch_row_logp(canopy_ctx* ctx, const canopy_model* model,
@@ -287,6 +329,10 @@ CANOPY_API canopy_status canopy_last_kernel_ms(canopy_ctx* ctx, double* row_kern
    resolved to); 0 before the first pass. */
 CANOPY_API int32_t canopy_last_kernel_variant(const canopy_ctx* ctx);
 
+/* FILTER_REFINE: rows the filter pass flagged for the exact pass, and the rows it looked at, as of the last
+   canopy_quantify_fetch / canopy_quantify of such a pass (CANOPY_ERR_STATE before the first). */
+CANOPY_API canopy_status canopy_last_filter_candidates(const canopy_ctx* ctx, int64_t* n_candidates, int64_t* n_rows);
+
 /* ---- captured passes (hipGraph) -------------------------------------------------------------------------- */
 /*
  * A small model is launch-bound (config 2: 1e5 cut sets, ~10 us of kernel time in 2-4 launches). canopy_graph_capture
@@ -295,6 +341,10 @@ CANOPY_API int32_t canopy_last_kernel_variant(const canopy_ctx* ctx);
  * gather buffer, canopy_fetch_keep_mask ...). The probabilities may be changed between launches
  * (canopy_model_set_probabilities writes the same device buffer); per-launch timing is not available for a replay.
  * The context, the model and its derived layouts must outlive the graph; capture once per (model, params).
+ * A graph holds raw pointers to the context's scratch and output buffers as they were at capture. Anything that
+ * replaces one of them afterwards -- an eager pass over a larger model, the first pass that asks for a per-row
+ * output or importance, canopy_ctx_set_gather_buffer / canopy_ctx_set_importance_buffer with another pointer --
+ * invalidates the graph: canopy_graph_launch then returns CANOPY_ERR_STATE and the pass must be captured again.
  */
 typedef struct canopy_graph canopy_graph;
 CANOPY_API canopy_status canopy_graph_capture(canopy_ctx* ctx, const canopy_model* model,
@@ -402,6 +452,9 @@ CANOPY_API canopy_status canopy_mc_fetch(canopy_ctx* ctx, canopy_mc_result* resu
 CANOPY_API canopy_status canopy_mc_run(canopy_ctx* ctx, const canopy_dag* dag, const canopy_mc_params* params,
                                        canopy_mc_result* result);
 
+/* Global {hits, trials} of the last canopy_mc_run_async on a context with a communicator (see canopy_comm_*). */
+CANOPY_API canopy_status canopy_comm_mc_fetch(canopy_comm* comm, canopy_mc_result* result);
+
 /* ---- K0: fault tree -> cut sets / gate DAG (host only, no device needed) --------------------------- */
 /*
  * A small reader for the Open-PSA Model Exchange Format subset that fault trees need
@@ -455,6 +508,10 @@ CANOPY_API canopy_status canopy_timing_begin(canopy_ctx* ctx, int32_t max_launch
 CANOPY_API canopy_status canopy_timing_end(canopy_ctx* ctx, double* row_kernel_ms_sum,
                                            double* total_ms_sum, int32_t* n_launches);
 
+/* Launch i (0-based) of the last closed timing region: device ms of its row kernel(s), and of the whole pass
+   (final reduce and, with a communicator, the all-reduce included). */
+CANOPY_API canopy_status canopy_timing_get(canopy_ctx* ctx, int32_t i, double* row_kernel_ms, double* total_ms);
+
 /* ---- synthetic inputs (host logic) ----------------------------------------------------------- */
 /* p_j = 10^(-8 + 5 u_j), u_j uniform [0,1) from the same counter-based generator: p[n_events]. */
 CANOPY_API canopy_status canopy_synthetic_probabilities(uint64_t seed, int32_t n_events, double* p);
@@ -466,6 +523,11 @@ CANOPY_API canopy_status canopy_synthetic_probabilities(uint64_t seed, int32_t n
  */
 CANOPY_API canopy_status canopy_shard_rows(const int64_t* row_ptr, int64_t n_rows, int32_t n_shards,
                                            int64_t* bounds);
+/* The same rule for rows [0, n_rows) of the synthetic family (canopy_model_synthetic) without materialising it on
+   the host: the row lengths are generated and scanned on the context's device (no columns), the bounds searched
+   there. Every rank of a strong-scaling run calls this and then generates only its own shard. */
+CANOPY_API canopy_status canopy_synthetic_shard_bounds(canopy_ctx* ctx, uint64_t seed, int64_t n_rows, int32_t avg_nnz,
+                                                       int32_t n_shards, int64_t* bounds);
 
 #ifdef __cplusplus
 }

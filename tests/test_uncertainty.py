@@ -19,10 +19,10 @@ def test_deviate_parametrisations_have_the_documented_moments(canopy_lib):
     assert np.all(t[:, 0] == 0.25)
     assert abs(m[1] - 0.2) < 1e-3 and abs(m[2] - 0.5) < 1e-3
     assert abs(m[3] - 1e-3) < 2e-5  # the mean parameter is the mean of the log-normal itself
-    # error factor: the 97.5 % quantile over the median equals EF at level 0.95 (two-sided)
-    med, hi = np.quantile(t[:, 3], [0.5, 0.975])
+    # error factor = quantile(level) / median: z_alpha is the one-sided upper quantile (random_deviate.h:109-111)
+    med, hi = np.quantile(t[:, 3], [0.5, 0.95])
     assert abs(hi / med - 3.0) < 0.05
-    med, hi = np.quantile(t[:, 4], [0.5, 0.95])
+    med, hi = np.quantile(t[:, 4], [0.5, 0.90])
     assert abs(hi / med - 10.0) < 0.3
     assert abs(np.median(t[:, 5]) - 1e-3) < 2e-5
     assert abs(m[6] - 0.02) < 2e-4 and abs(m[7] - 0.2) < 1e-3
