@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--also-steps", type=int, default=30)
     ap.add_argument("--collective", choices=("lib", "torch"), default="lib",
                     help="lib: canopy_comm_* (ncclAllReduce issued by libcanopy.so); torch: torch.distributed all_reduce")
+    ap.add_argument("--serial-collective", action="store_true",
+                    help="A/B: the all-reduce on the pass's own stream instead of the communicator's (CANOPY_COMM_SERIAL=1)")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="single-GPU rehearsal of a strong-scaling shard: run shard 0 of an N-way split of --rows")
     ap.add_argument("--rehearse-backend", default="",
@@ -112,6 +114,8 @@ def main():
                     help="rehearse the N>1 code path (communicator, gather slots, all-reduce) at world size 1")
     args = ap.parse_args()
 
+    if args.serial_collective:
+        os.environ["CANOPY_COMM_SERIAL"] = "1"
     import torch  # first: one HIP runtime shared in-process
     import torch.distributed as dist
     import canopy_amd
@@ -223,8 +227,10 @@ def main():
     k_ms_sum, tot_ms_sum, n_timed = ctx.timing_end()
     launches = ctx.timing_launches(n_timed)
 
+    collective_ms = None
     if comm is not None:
         result = comm.fetch()
+        collective_ms = comm.last_collective_ms()
     elif comb is not None:
         with torch.cuda.stream(tstream):
             result = comb.result()
@@ -302,7 +308,8 @@ def main():
                                "one GPU" if world == 1 else "%s scaling over %d ranks" % (args.scaling, world),
                                info.n_rows, args.avg_nnz, args.cut_off,
                                "; %.2f %% of the rows pass the conservative filter into the exact pass, %.2f %% survive the cut-off"
-                               % (100 * cand_frac, 100.0 * result.n_kept / max(total_rows, 1)) if cand_frac is not None else ""),
+                               % (100 * cand_frac, 100.0 * result.n_kept / max(total_rows if use_dist and not args.force_dist else info.n_rows, 1))
+                               if cand_frac is not None else ""),
                 "total_rows": total_rows, "rows_this_rank": info.n_rows, "first_row_this_rank": first_row,
                 "nnz_this_rank": info.nnz, "n_events": info.n_events,
                 "sharding": ("contiguous nnz-balanced row shards (canopy_shard_rows rule), %d rank(s); " % world + collective)
@@ -325,6 +332,9 @@ def main():
                 "avg_kernel_ms": k_mean, "median_kernel_ms": k_med, "min_kernel_ms": k_min,
                 "avg_pass_ms": p_mean, "median_pass_ms": p_med, "min_pass_ms": p_min, "launches_timed": n_timed,
                 "host_enqueue_ms_per_step": t_enqueued * 1e3 / args.steps,
+                "last_collective_ms": collective_ms,
+                "collective_stream": None if comm is None else ("pass stream (serial)" if args.serial_collective else
+                                                                "own stream, overlapping the next pass"),
             },
             "result": {"rare_event": result.rare_event, "mcub": result.mcub, "n_kept": result.n_kept,
                        "argmax_row": result.argmax_row},

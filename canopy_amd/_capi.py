@@ -31,7 +31,7 @@ APPROX_RARE_EVENT, APPROX_MCUB, APPROX_BOTH = 1, 2, 3
 QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK, QUANT_IMPORTANCE = 1, 2, 4, 8
 BATCH_LOG_INPUT = 1
 GATE_AND, GATE_OR, GATE_ATLEAST, GATE_XOR, GATE_NOT, GATE_NAND, GATE_NOR, GATE_NULL = range(8)
-KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER, KERNEL_FILTER_REFINE = range(6)
+KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER, KERNEL_FILTER_REFINE, KERNEL_FIXED_SUM = range(7)
 
 
 class CtxParams(C.Structure):
@@ -123,6 +123,7 @@ SIGNATURES = {
     "canopy_comm_quantify_all_async": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
                                                  C.POINTER(QuantParams)]),
     "canopy_comm_fetch": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(QuantResult), C.POINTER(Partial)]),
+    "canopy_comm_last_collective_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "canopy_comm_mc_fetch": (C.c_int, [C.c_void_p, C.POINTER(McResult)]),
     "canopy_synthetic_shard_bounds": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "canopy_combine_partials": (C.c_int, [C.POINTER(Partial), C.c_int32, C.c_uint32, C.POINTER(QuantResult)]),

@@ -61,6 +61,8 @@ void free_model_buffers(canopy_model* m) {
     if (m->d_logp) (void)hipFree(m->d_logp);
     if (m->d_q8) (void)hipFree(m->d_q8);
     m->d_q8 = nullptr;
+    if (m->d_fx) (void)hipFree(m->d_fx);
+    m->d_fx = nullptr; m->fx_version = 0;
     if (m->d_ws_stream) (void)hipFree(m->d_ws_stream);
     if (m->d_ws_off) (void)hipFree(m->d_ws_off);
     if (m->d_vs_stream) (void)hipFree(m->d_vs_stream);
@@ -422,10 +424,12 @@ extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, 
         if (m->fr_state == 1) return CANOPY_OK;
     }
     if (variant == CANOPY_KERNEL_ROWS || variant == CANOPY_KERNEL_ROWS_LDS) return CANOPY_OK;
-    if (variant == CANOPY_KERNEL_FILTER_REFINE) {
+    if (variant == CANOPY_KERNEL_FILTER_REFINE || variant == CANOPY_KERNEL_FIXED_SUM) { // both read the slab stream
         canopy_status st = build_fr(ctx, m);
         if (st != CANOPY_OK) return st;
         if (m->fr_state != 1) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a filter/refine stream");
+        if (variant == CANOPY_KERNEL_FIXED_SUM && m->max_row_len > fx_max_row_len())
+            return fail(ctx, CANOPY_ERR_UNSUPPORTED, "FIXED_SUM needs rows of at most 63 entries");
         return CANOPY_OK;
     }
     if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
@@ -472,15 +476,30 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         if (pst != CANOPY_OK) return pst;
         if (m->fr_state == 1) variant = CANOPY_KERNEL_FILTER_REFINE;
     }
-    if (variant == CANOPY_KERNEL_FILTER_REFINE) {
-        if (!(params->cut_off > 0.0) || want_rows_early)
-            return fail(ctx, CANOPY_ERR_UNSUPPORTED, "FILTER_REFINE needs cut_off > 0 and no per-row output");
+    // AUTO, sum-only pass that filter/refine does not serve (cut_off = 0, or a cut-off most rows survive): the
+    // order-independent fixed-point pass instead of the exact CSR-order stream kernel, unless IT had to hand > 20 % of
+    // the rows to the exact pass last time (huge |s|, clamped entries)
+    if (params->kernel == CANOPY_KERNEL_AUTO && variant == CANOPY_KERNEL_WAVE_STREAM && !want_rows_early &&
+        m->n_events >= 1 && m->n_events <= fr_max_events() && m->n_rows >= (int64_t)1000000 && m->max_row_len <= fx_max_row_len() &&
+        !(ctx->fx_known_id == m->id && ctx->fx_known_fraction > 0.2 && ctx->fx_known_cut_off == params->cut_off &&
+          ctx->fx_known_version == m->logp_version)) {
+        canopy_status pst = build_fr(ctx, const_cast<canopy_model*>(m));
+        if (pst != CANOPY_OK) return pst;
+        if (m->fr_state == 1) variant = CANOPY_KERNEL_FIXED_SUM;
+    }
+    if (variant == CANOPY_KERNEL_FILTER_REFINE || variant == CANOPY_KERNEL_FIXED_SUM) {
+        if (variant == CANOPY_KERNEL_FILTER_REFINE && !(params->cut_off > 0.0))
+            return fail(ctx, CANOPY_ERR_UNSUPPORTED, "FILTER_REFINE needs cut_off > 0");
+        if (want_rows_early)
+            return fail(ctx, CANOPY_ERR_UNSUPPORTED, "FILTER_REFINE / FIXED_SUM have no per-row output (bit-exact s_i needs the CSR order)");
+        if (variant == CANOPY_KERNEL_FIXED_SUM && m->max_row_len > fx_max_row_len())
+            return fail(ctx, CANOPY_ERR_UNSUPPORTED, "FIXED_SUM needs rows of at most 63 entries");
         canopy_status pst = build_fr(ctx, const_cast<canopy_model*>(m));
         if (pst != CANOPY_OK) return pst;
         if (m->fr_state != 1) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a filter/refine stream");
     }
     if (variant != CANOPY_KERNEL_ROWS && variant != CANOPY_KERNEL_ROWS_LDS && variant != CANOPY_KERNEL_WAVE_STREAM &&
-        variant != CANOPY_KERNEL_VALUE_SCATTER && variant != CANOPY_KERNEL_FILTER_REFINE)
+        variant != CANOPY_KERNEL_VALUE_SCATTER && variant != CANOPY_KERNEL_FILTER_REFINE && variant != CANOPY_KERNEL_FIXED_SUM)
         return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
     if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
         canopy_status pst = build_vs(ctx, const_cast<canopy_model*>(m)); // lazy, one-off, independent of p
@@ -533,12 +552,13 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : ws_default_grid(ctx->n_cu, m->n_ws);
     else if (variant == CANOPY_KERNEL_VALUE_SCATTER)
         grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : vs_default_grid(ctx->n_cu, m->n_slabs);
-    else if (variant == CANOPY_KERNEL_FILTER_REFINE)
+    else if (variant == CANOPY_KERNEL_FILTER_REFINE || variant == CANOPY_KERNEL_FIXED_SUM)
         grid = fr_refine_grid(ctx->n_cu);
     else
         grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override
                                           : rows_kernel_default_grid(ctx->n_cu, variant, m->n_rows);
-    canopy_status st = ensure_block_partials(ctx, variant == CANOPY_KERNEL_WAVE_STREAM ? grid * 4 : grid);
+    const int grid_fx = variant == CANOPY_KERNEL_FIXED_SUM ? fx_sum_grid(ctx->n_cu, m->n_events, m->n_fr_slabs) : 0;
+    canopy_status st = ensure_block_partials(ctx, variant == CANOPY_KERNEL_WAVE_STREAM ? grid * 4 : grid + grid_fx);
     if (st != CANOPY_OK) return st;
 
     RowKernelArgs a;
@@ -550,6 +570,10 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     a.row_logp_out = want_rows ? ctx->d_row_logp : nullptr;
     a.keep_mask_out = want_mask ? ctx->d_keep_mask : nullptr;
 
+    if (ctx->comm) { // this pass's slot buffer (two alternate, so the collective can trail the next pass's kernels)
+        canopy_status cst = comm_begin_pass(ctx);
+        if (cst != CANOPY_OK) return cst;
+    }
     hipEvent_t* ev = ctx->ev_last;
     if (ctx->timing_on && !ctx->capturing && ctx->timing_n < ctx->timing_max) {
         ev = &ctx->ev_pool[(size_t)ctx->timing_n * 3];
@@ -561,7 +585,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
     }
     if (!ctx->capturing) HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
-    if (variant == CANOPY_KERNEL_FILTER_REFINE) {
+    if (variant == CANOPY_KERNEL_FILTER_REFINE || variant == CANOPY_KERNEL_FIXED_SUM) {
         // delta covers the rounding difference between the unordered pass-A sum and the CSR-order sum
         const double cand_cut = a.log_cut - (1e-9 + 1e-11 * (double)m->max_row_len);
         if (!ctx->d_fr_count) {
@@ -574,6 +598,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         ctx->fr_pending_rows = m->n_rows;
         ctx->fr_pending_cut_off = params->cut_off;
         ctx->fr_pending_version = m->logp_version;
+        ctx->fr_pending_variant = variant;
         const int slab_rows = fr_slab_rows(m->n_events);
         const int64_t list_len = m->n_fr_slabs * slab_rows;
         if (ctx->fr_list_cap < list_len || !ctx->d_fr_list) {
@@ -588,9 +613,21 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             HIP_TRY(ctx, hipMalloc(&ctx->d_fr_cnt, sizeof(unsigned) * (size_t)(m->n_fr_slabs > 0 ? m->n_fr_slabs : 1)));
             ctx->fr_cnt_cap = m->n_fr_slabs; ++ctx->scratch_gen;
         }
-        if (want_mask) // the refine pass ORs the exact keep bits into a cleared mask
+        if (want_mask && variant == CANOPY_KERNEL_FILTER_REFINE) // the refine pass ORs the exact keep bits into a cleared mask
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
-        if (fr_filter_is_quantised(m->n_events)) {
+        if (variant == CANOPY_KERNEL_FIXED_SUM) {
+            canopy_model* mm = const_cast<canopy_model*>(m);
+            if (!mm->d_fx) HIP_TRY(ctx, hipMalloc(&mm->d_fx, sizeof(uint64_t) * (size_t)(m->n_events > 0 ? m->n_events : 1)));
+            if (ctx->capturing || mm->fx_version != m->logp_version || mm->fx_version == 0) { // (a captured pass always rebuilds it)
+                HIP_TRY(ctx, launch_fx_table(m->d_logp, m->n_events, mm->d_fx, ctx->stream));
+                mm->fx_version = m->logp_version;
+            }
+            // pass A writes records [0, grid_fx) and every word of the keep mask; the exact pass adds records [grid_fx, ..)
+            HIP_TRY(ctx, launch_fx_sum(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, mm->d_fx, m->d_row_ptr, m->n_rows, m->n_events,
+                                       m->n_fr_slabs, a.log_cut, params->limit_order, m->max_row_len, ctx->d_block_partials,
+                                       ctx->d_fr_list, ctx->d_fr_cnt, ctx->d_fr_count, want_mask ? ctx->d_keep_mask : nullptr,
+                                       grid_fx, ctx->stream));
+        } else if (fr_filter_is_quantised(m->n_events)) {
             canopy_model* mm = const_cast<canopy_model*>(m);
             if (!mm->d_q8) HIP_TRY(ctx, hipMalloc(&mm->d_q8, (((size_t)m->n_events + 15) / 16) * 16 + 16));
             // the 8-bit table depends on (logp, cut-off) only: rebuilt when either changed
@@ -606,7 +643,9 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
                                       m->n_events, m->n_fr_slabs, cand_cut, ctx->d_fr_list, ctx->d_fr_cnt, ctx->d_fr_count, ctx->n_cu,
                                       ctx->stream));
         HIP_TRY(ctx, launch_fr_refine(a, ctx->d_fr_list, ctx->d_fr_cnt, slab_rows, m->n_fr_slabs,
-                                      want_mask ? ctx->d_keep_mask : nullptr, grid, ctx->stream));
+                                      want_mask ? ctx->d_keep_mask : nullptr, grid, variant == CANOPY_KERNEL_FIXED_SUM, grid_fx,
+                                      ctx->stream));
+        n_records = grid + grid_fx;
     } else if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
         HIP_TRY(ctx, launch_vs_kernel(a, m->d_vs_stream, m->d_vs_off, m->d_vs_slab_row, m->vs_total_chunks, m->n_slabs,
                                       grid, ctx->stream));
@@ -619,7 +658,9 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     }
     if (!ctx->capturing) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     HIP_TRY(ctx, launch_finalize(ctx->d_block_partials, n_records, ctx->d_partial, ctx->d_gather, ctx->gather_world,
-                                 ctx->gather_rank, variant == CANOPY_KERNEL_FILTER_REFINE ? ctx->d_fr_count : nullptr, ctx->stream));
+                                 ctx->gather_rank,
+                                 (variant == CANOPY_KERNEL_FILTER_REFINE || variant == CANOPY_KERNEL_FIXED_SUM) ? ctx->d_fr_count : nullptr,
+                                 ctx->stream));
     ctx->last_variant = variant;
     if (ctx->comm) { // K5: the one collective of the path, same stream, issued here (not by the host language)
         canopy_status cst = comm_all_reduce_partials(ctx);
@@ -648,11 +689,20 @@ canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* out) try {
                                     ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out, ctx->h_partial, sizeof(canopy_partial));
-    if (ctx->fr_pending_id) { // feedback for AUTO: a filter that flags most rows is not worth its refine pass
-        ctx->fr_known_id = ctx->fr_pending_id;
-        ctx->fr_known_cut_off = ctx->fr_pending_cut_off;
-        ctx->fr_known_version = ctx->fr_pending_version;
-        ctx->fr_known_fraction = ctx->fr_pending_rows > 0 ? (double)*ctx->h_fr_count / (double)ctx->fr_pending_rows : 0.0;
+    if (ctx->fr_pending_id) { // feedback for AUTO: a pass A that lists most rows is not worth its exact pass
+        const double frac = ctx->fr_pending_rows > 0 ? (double)*ctx->h_fr_count / (double)ctx->fr_pending_rows : 0.0;
+        if (ctx->fr_pending_variant == CANOPY_KERNEL_FIXED_SUM) {
+            ctx->fx_known_id = ctx->fr_pending_id;
+            ctx->fx_known_cut_off = ctx->fr_pending_cut_off;
+            ctx->fx_known_version = ctx->fr_pending_version;
+            ctx->fx_known_fraction = frac;
+        } else {
+            ctx->fr_known_id = ctx->fr_pending_id;
+            ctx->fr_known_cut_off = ctx->fr_pending_cut_off;
+            ctx->fr_known_version = ctx->fr_pending_version;
+            ctx->fr_known_fraction = frac;
+        }
+        ctx->fr_known_variant = ctx->fr_pending_variant;
         ctx->fr_known_count = (int64_t)*ctx->h_fr_count;
         ctx->fr_known_rows = ctx->fr_pending_rows;
         ctx->fr_pending_id = 0;
@@ -865,7 +915,7 @@ canopy_status canopy_timing_get(canopy_ctx* ctx, int32_t i, double* row_kernel_m
 } CANOPY_CATCH_ALL
 
 canopy_status canopy_last_filter_candidates(const canopy_ctx* ctx, int64_t* n_candidates, int64_t* n_rows) {
-    if (!ctx || ctx->fr_known_id == 0) return CANOPY_ERR_STATE;
+    if (!ctx || ctx->fr_known_variant == 0) return CANOPY_ERR_STATE;
     if (n_candidates) *n_candidates = ctx->fr_known_count;
     if (n_rows) *n_rows = ctx->fr_known_rows;
     return CANOPY_OK;

@@ -64,6 +64,10 @@ struct canopy_ctx {
     int64_t fr_known_count = 0, fr_known_rows = 0;
     double fr_known_cut_off = -1.0, fr_pending_cut_off = -1.0; // the feedback applies to the same (model, p, cut-off) only
     uint64_t fr_known_version = 0, fr_pending_version = 0;
+    int32_t fr_pending_variant = 0, fr_known_variant = 0; // FILTER_REFINE or FIXED_SUM: whose list the count belongs to
+    // the same feedback for FIXED_SUM (rows it had to leave to the exact pass), kept apart from the filter's
+    uint64_t fx_known_id = 0, fx_known_version = 0;
+    double fx_known_fraction = -1.0, fx_known_cut_off = -1.0;
     // K6 Monte-Carlo
     unsigned long long* d_mc_hits = nullptr; // [1]
     unsigned long long* h_mc_hits = nullptr; // pinned
@@ -82,8 +86,15 @@ struct canopy_comm {
     canopy_ctx* ctx = nullptr;
     void* comm = nullptr;   // ncclComm_t
     int world = 1, rank = 0;
-    double* d_buf = nullptr; // [world][8] gather slots = the all-reduce buffer
-    double* h_buf = nullptr; // pinned mirror
+    double* d_buf = nullptr; // [2][world][8] gather slots = the all-reduce buffers (two: consecutive passes alternate)
+    double* h_buf = nullptr; // pinned mirror of one of them
+    // The collective runs on its OWN stream behind an event of the pass's final reduce, so the next pass's kernels
+    // start while the (latency-bound, world * 64 B) all-reduce of this one is still on the wire.
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_fin[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    int next = 0, last = -1; // buffer of the pass being enqueued / of the last enqueued pass
+    bool overlap = true;     // false (CANOPY_COMM_SERIAL=1): collective on the context's stream, one buffer
     unsigned long long* d_mc = nullptr; // [2] {hits, trials} of the Monte-Carlo combine
     unsigned long long* h_mc = nullptr;
     bool mc_valid = false;
@@ -121,6 +132,8 @@ struct canopy_model {
     double* d_logp = nullptr;     // [n_events]
     uint8_t* d_q8 = nullptr;      // [n_events rounded up to 16] quantised -logp of the FILTER_REFINE filter pass
     uint64_t logp_version = 0;    // bumped whenever d_logp's contents (or the pointer) change
+    uint64_t* d_fx = nullptr;     // [n_events] fixed-point -logp * 2^47 of the FIXED_SUM pass
+    uint64_t fx_version = 0;      // logp_version d_fx was built from (0 = none)
     uint64_t q8_version = 0;      // logp_version the table in d_q8 was built from (0 = none)
     double q8_log_cut = 0.0;      // ... and the log cut-off it was built for
     bool has_p = false;
@@ -184,6 +197,7 @@ hipError_t synth_build_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int
 
 
 // comm_rccl.hip
+canopy_status comm_begin_pass(canopy_ctx* ctx);
 canopy_status comm_all_reduce_partials(canopy_ctx* ctx);
 canopy_status comm_all_reduce_mc(canopy_ctx* ctx, const unsigned long long* d_hits, long long trials);
 
@@ -227,7 +241,15 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
                                uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs, double log_cut,
                                uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count, int n_cu,
                                bool table_valid, hipStream_t s);
+// flagged: the lists come from launch_fx_sum (flag bits 15 / 14 per entry); records go to block_partials[part_offset + block]
 hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, const unsigned* cand_cnt, int slab_rows,
-                            int64_t n_slabs, uint64_t* keep_mask, int grid, hipStream_t s);
+                            int64_t n_slabs, uint64_t* keep_mask, int grid, bool flagged, int part_offset, hipStream_t s);
+int fx_max_row_len();
+int fx_sum_grid(int n_cu, int32_t n_events, int64_t n_slabs);
+hipError_t launch_fx_table(const double* logp, int32_t n_events, uint64_t* fx, hipStream_t s);
+hipError_t launch_fx_sum(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const uint64_t* fx,
+                         const int64_t* row_ptr, int64_t n_rows, int32_t n_events, int64_t n_slabs, double log_cut,
+                         int32_t limit_order, int32_t max_row_len, double* block_partials, uint16_t* cand_list,
+                         unsigned* cand_cnt, unsigned long long* cand_count, uint64_t* keep_mask, int grid, hipStream_t s);
 
 } // namespace canopy

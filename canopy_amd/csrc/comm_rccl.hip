@@ -16,6 +16,7 @@
 // a process that already carries an RCCL (a PyTorch-ROCm process) shares that copy instead of loading a second.
 #include <dlfcn.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -99,24 +100,42 @@ canopy_status comm_fail(canopy_ctx* ctx, canopy_status st, const std::string& ms
         }                                                                                              \
     } while (0)
 
+void comm_release(canopy_comm* c) { // device / host resources only (not the RCCL communicator)
+    if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->h_buf) (void)hipHostFree(c->h_buf);
+    if (c->d_mc) (void)hipFree(c->d_mc);
+    if (c->h_mc) (void)hipHostFree(c->h_mc);
+    for (int b = 0; b < 2; ++b) {
+        if (c->ev_fin[b]) (void)hipEventDestroy(c->ev_fin[b]);
+        if (c->ev_done[b]) (void)hipEventDestroy(c->ev_done[b]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+double* comm_buf(const canopy_comm* c, int b) { return c->d_buf + (size_t)b * CANOPY_PARTIAL_DOUBLES * (size_t)c->world; }
+
 canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, canopy_comm** out) {
     canopy_comm* c = new (std::nothrow) canopy_comm();
     if (!c) return CANOPY_ERR_OUT_OF_MEMORY;
     c->ctx = ctx; c->comm = nc; c->world = world; c->rank = rank;
     HIPC_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bytes = sizeof(double) * CANOPY_PARTIAL_DOUBLES * (size_t)world;
-    hipError_t e = hipMalloc(&c->d_buf, bytes);
+    static const bool serial = getenv("CANOPY_COMM_SERIAL") != nullptr; // A/B switch: collective on the pass's own stream
+    c->overlap = !serial;
+    hipError_t e = hipMalloc(&c->d_buf, 2 * bytes);
     if (e == hipSuccess) e = hipHostMalloc(&c->h_buf, bytes);
+    if (e == hipSuccess && c->overlap) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        e = hipEventCreate(&c->ev_fin[b]);
+        if (e == hipSuccess) e = hipEventCreate(&c->ev_done[b]);
+    }
     if (e == hipSuccess) e = hipMalloc(&c->d_mc, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_mc, 2 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_buf, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_buf, 0, 2 * bytes, ctx->stream);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        if (c->d_buf) (void)hipFree(c->d_buf);
-        if (c->h_buf) (void)hipHostFree(c->h_buf);
-        if (c->d_mc) (void)hipFree(c->d_mc);
-        if (c->h_mc) (void)hipHostFree(c->h_mc);
-        delete c;
+        comm_release(c);
         return comm_fail(ctx, CANOPY_ERR_OUT_OF_MEMORY, std::string("comm buffers: ") + hipGetErrorString(e));
     }
     // every later pass on this context fills slot `rank` and runs the collective
@@ -131,12 +150,40 @@ canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, ca
 
 namespace canopy {
 
-// Called by canopy_quantify_async right behind k_finalize (same stream, no host round trip).
+// Called by canopy_quantify_async before it launches anything: picks the slot buffer of this pass. A buffer is reused
+// every second pass; its previous all-reduce must have finished before k_finalize overwrites it (an event wait on the
+// device, no host blocking -- by then it normally has).
+canopy_status comm_begin_pass(canopy_ctx* ctx) {
+    canopy_comm* c = ctx->comm;
+    if (!c) return CANOPY_OK;
+    const int b = (c->overlap && !c->deferred) ? c->next : 0;
+    if (c->overlap && !c->deferred && c->used[b]) HIPC_TRY(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done[b], 0));
+    ctx->d_gather = comm_buf(c, b); // (same world / rank as set at attach time)
+    return CANOPY_OK;
+}
+
+// Called by canopy_quantify_async right behind k_finalize: no host round trip. The collective goes to the
+// communicator's own stream behind an event, so the context's stream is free for the next pass at once.
 canopy_status comm_all_reduce_partials(canopy_ctx* ctx) {
     canopy_comm* c = ctx->comm;
     if (!c || c->deferred) return CANOPY_OK;
-    RCCL_TRY(ctx, rccl()->AllReduce(c->d_buf, c->d_buf, (size_t)c->world * CANOPY_PARTIAL_DOUBLES, ncclDouble, ncclSum,
-                                    static_cast<ncclComm_t>(c->comm), ctx->stream));
+    const size_t count = (size_t)c->world * CANOPY_PARTIAL_DOUBLES;
+    if (!c->overlap) {
+        HIPC_TRY(ctx, hipEventRecord(c->ev_fin[0], ctx->stream));
+        RCCL_TRY(ctx, rccl()->AllReduce(c->d_buf, c->d_buf, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(c->comm), ctx->stream));
+        HIPC_TRY(ctx, hipEventRecord(c->ev_done[0], ctx->stream));
+        c->last = 0; c->used[0] = true;
+        return CANOPY_OK;
+    }
+    const int b = c->next;
+    double* buf = comm_buf(c, b);
+    HIPC_TRY(ctx, hipEventRecord(c->ev_fin[b], ctx->stream));
+    HIPC_TRY(ctx, hipStreamWaitEvent(c->stream, c->ev_fin[b], 0));
+    RCCL_TRY(ctx, rccl()->AllReduce(buf, buf, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(c->comm), c->stream));
+    HIPC_TRY(ctx, hipEventRecord(c->ev_done[b], c->stream));
+    c->used[b] = true;
+    c->last = b;
+    c->next = b ^ 1;
     return CANOPY_OK;
 }
 
@@ -221,15 +268,12 @@ void canopy_comm_free(canopy_comm* c) {
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         if (ctx->comm == c) {
             ctx->comm = nullptr;
-            if (ctx->d_gather == c->d_buf) (void)canopy_ctx_set_gather_buffer(ctx, nullptr, 0, 0);
+            (void)canopy_ctx_set_gather_buffer(ctx, nullptr, 0, 0);
         }
     }
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl()->handle) (void)rccl()->CommDestroy(static_cast<ncclComm_t>(c->comm));
-    if (c->d_buf) (void)hipFree(c->d_buf);
-    if (c->h_buf) (void)hipHostFree(c->h_buf);
-    if (c->d_mc) (void)hipFree(c->d_mc);
-    if (c->h_mc) (void)hipHostFree(c->h_mc);
-    delete c;
+    comm_release(c);
 }
 
 canopy_status canopy_comm_info(const canopy_comm* c, int32_t* world_size, int32_t* rank, int32_t* rccl_version) try {
@@ -262,6 +306,7 @@ canopy_status canopy_comm_quantify_all_async(canopy_comm* const* comms, const ca
     RCCL_TRY(c0, api->GroupStart());
     for (int i = 0; i < n; ++i) {
         canopy_comm* c = comms[i];
+        c->last = 0;
         ncclResult_t r = api->AllReduce(c->d_buf, c->d_buf, (size_t)c->world * CANOPY_PARTIAL_DOUBLES, ncclDouble, ncclSum,
                                         static_cast<ncclComm_t>(c->comm), c->ctx->stream);
         if (r != ncclSuccess) {
@@ -277,13 +322,26 @@ canopy_status canopy_comm_fetch(canopy_comm* c, uint32_t flags, canopy_quant_res
     if (!c || !c->ctx || (!result && !parts)) return CANOPY_ERR_INVALID_ARGUMENT;
     canopy_ctx* ctx = c->ctx;
     HIPC_TRY(ctx, hipSetDevice(ctx->device));
+    if (c->last < 0) return comm_fail(ctx, CANOPY_ERR_STATE, "no pass has been enqueued since the communicator was attached");
     const size_t bytes = sizeof(double) * CANOPY_PARTIAL_DOUBLES * (size_t)c->world;
-    HIPC_TRY(ctx, hipMemcpyAsync(c->h_buf, c->d_buf, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t cs = (c->overlap && !c->deferred) ? c->stream : ctx->stream; // the stream the collective ran on
+    HIPC_TRY(ctx, hipMemcpyAsync(c->h_buf, comm_buf(c, c->last), bytes, hipMemcpyDeviceToHost, cs));
+    HIPC_TRY(ctx, hipStreamSynchronize(cs));
     static_assert(sizeof(canopy_partial) == sizeof(double) * CANOPY_PARTIAL_DOUBLES, "record layout");
     const canopy_partial* recs = reinterpret_cast<const canopy_partial*>(c->h_buf);
     if (parts) memcpy(parts, recs, bytes);
     if (result) return canopy_combine_partials(recs, c->world, flags, result); // rank order: the same on every rank
+    return CANOPY_OK;
+} CANOPY_CATCH_ALL
+
+canopy_status canopy_comm_last_collective_ms(canopy_comm* c, double* ms) try {
+    if (!c || !c->ctx || !ms) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (c->last < 0 || c->deferred) return comm_fail(c->ctx, CANOPY_ERR_STATE, "no collective to time");
+    HIPC_TRY(c->ctx, hipSetDevice(c->ctx->device));
+    HIPC_TRY(c->ctx, hipEventSynchronize(c->ev_done[c->last]));
+    float t = 0.f;
+    HIPC_TRY(c->ctx, hipEventElapsedTime(&t, c->ev_fin[c->last], c->ev_done[c->last]));
+    *ms = t;
     return CANOPY_OK;
 } CANOPY_CATCH_ALL
 

@@ -149,8 +149,9 @@ __device__ __forceinline__ void fr_barrier() { // LDS drained, then the workgrou
 // lane) order: every wave publishes popcount(m[i]) to s_cnt[i * NW + wave], one workgroup barrier, every
 // wave scans all NI * NW counts and writes its own candidates. Positions never depend on timing.
 template <int NI, int NW>
-__device__ __forceinline__ unsigned fr_emit_candidates(const unsigned long long (&m)[NI], const unsigned* s_cnt, int lane,
-                                                       int wave, int tid, uint16_t* __restrict__ seg) {
+__device__ __forceinline__ unsigned fr_emit_candidates(const unsigned long long (&m)[NI], const unsigned (&fl)[NI],
+                                                       const unsigned* s_cnt, int lane, int wave, int tid,
+                                                       uint16_t* __restrict__ seg) {
     constexpr int NC = NI * NW, PER = NC / kWave;
     static_assert(NC % kWave == 0 && (PER == 2 || PER == 4), "counts per lane");
     unsigned c[PER], offs[PER], tot = 0;
@@ -175,7 +176,7 @@ __device__ __forceinline__ unsigned fr_emit_candidates(const unsigned long long 
         const unsigned off = __shfl(sel, idx / PER, kWave);
         if ((m[i] >> lane) & 1ULL)
             seg[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[i], 0u))] =
-                (uint16_t)(i * (NW * kWave) + tid);
+                (uint16_t)(fl[i] | (unsigned)(i * (NW * kWave) + tid)); // fl: the fixed-point pass's flag bits (0 for the filters)
     }
     return total;
 }
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const u
         }
         if (tid < 64) sums[kFrSlabRows + tid] = 0.0; // the sink
         fr_barrier();
-        const unsigned total = fr_emit_candidates<NI, kFrWaves>(m, s_cnt, lane, wave, tid, cand_list + s * kFrSlabRows);
+        const unsigned no_flags[NI] = {};
+        const unsigned total = fr_emit_candidates<NI, kFrWaves>(m, no_flags, s_cnt, lane, wave, tid, cand_list + s * kFrSlabRows);
         if (tid == 0) cand_cnt[s] = total;
         n_cand += total; // wave-uniform
     }
@@ -375,7 +377,8 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
         }
         if (tid < 64) sums[kQ8SlabRows + tid] = 0u; // the sink
         fr_barrier();
-        const unsigned total = fr_emit_candidates<NI, kQ8Waves>(m, s_cnt, lane, wave, tid, cand_list + s * kQ8SlabRows);
+        const unsigned no_flags[NI] = {};
+        const unsigned total = fr_emit_candidates<NI, kQ8Waves>(m, no_flags, s_cnt, lane, wave, tid, cand_list + s * kQ8SlabRows);
         if (tid == 0) cand_cnt[s] = total;
         n_cand += total; // workgroup-uniform
     }
@@ -407,9 +410,14 @@ __device__ __forceinline__ double refine_row_sum(const RowKernelArgs& a, int64_t
     return s;
 }
 
+// FLAGGED (lists of the fixed-point pass k_fx_sum): bit 15 of an entry = "pass A left this row out: account for it
+// here if it is kept", bit 14 = "argmax contender: its exact s_i takes part in max / argmax"; the filters' lists carry
+// no flags and mean both. Records go to block_partials[part_offset + blockIdx.x].
+template <bool FLAGGED>
 __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArgs a, const uint16_t* __restrict__ cand_list,
                                                                    const unsigned* __restrict__ cand_cnt, int slab_rows,
-                                                                   int64_t n_slabs, uint64_t* __restrict__ keep_mask) {
+                                                                   int64_t n_slabs, uint64_t* __restrict__ keep_mask,
+                                                                   int part_offset) {
     __shared__ double s_red[kRefineWaves * kAccDoubles];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -423,16 +431,19 @@ __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArg
         const int64_t base = s * slab_rows;
         for (int j0 = (int)(u & 1) * kWave; j0 < n; j0 += 2 * kWave) {
             const bool on = j0 + lane < n;
-            const int64_t r = base + (on ? (int64_t)cand_list[base + j0 + lane] : 0);
+            const unsigned entry = on ? (unsigned)cand_list[base + j0 + lane] : 0u;
+            const bool account = !FLAGGED || (entry & 0x8000u) != 0, contend = !FLAGGED || (entry & 0x4000u) != 0;
+            const int64_t r = base + (int64_t)(FLAGGED ? (entry & 0x3FFFu) : entry);
             int len = 0;
             const double sv = on ? refine_row_sum(a, r, &len) : 0.0;
             const bool keep = on && (sv >= a.log_cut) && (a.limit_order == 0 || len <= a.limit_order);
-            fold_kept_row(acc.rare, acc.l1p, acc.n_certain, sv, keep);
+            fold_kept_row(acc.rare, acc.l1p, acc.n_certain, sv, keep && account);
             if (keep) {
-                acc.n_kept += 1.0;
+                if (account) acc.n_kept += 1.0;
                 // rows arrive in ascending order per lane, ties resolve to the lower row in acc_merge
-                if (sv > acc.max_logp) { acc.max_logp = sv; acc.argmax = (double)(a.row_offset + r); }
-                if (keep_mask != nullptr) atomicOr(reinterpret_cast<unsigned long long*>(&keep_mask[r >> 6]), 1ULL << (r & 63));
+                if (contend && sv > acc.max_logp) { acc.max_logp = sv; acc.argmax = (double)(a.row_offset + r); }
+                if (account && keep_mask != nullptr)
+                    atomicOr(reinterpret_cast<unsigned long long*>(&keep_mask[r >> 6]), 1ULL << (r & 63));
             }
         }
     }
@@ -447,7 +458,216 @@ __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArg
             acc_load(o, s_red + k * kAccDoubles);
             acc_merge(t, o);
         }
-        acc_store(a.block_partials + (size_t)blockIdx.x * kAccDoubles, t);
+        acc_store(a.block_partials + (size_t)(part_offset + (int)blockIdx.x) * kAccDoubles, t);
+    }
+}
+
+// ---- the exact all-rows pass without ordering constraints: fixed-point sums ----------------------------------
+// cut_off = 0, or a cut-off most rows survive: every row contributes, so there is nothing to filter, and the exact
+// CSR-order kernels pay for their ordering (k_ws: one wave per 4096 rows, gather and LDS phases serialised).
+// The contract only needs the ORDER for the bit-exact outputs (which rows are kept, which row is the argmax):
+// rare-event and MCUB carry a 1e-12 tolerance. So this pass adds in ANY order, exactly:
+//   fx[j]  = round(-logp[j] * 2^47)                (u64, clamped to 2^56; built when p changes)
+//   F_i    = sum of fx over the row                (integer adds commute: ds_add_u64, all 16 waves share a slab and
+//                                                   the column-sorted stream of the filter pass; deterministic)
+//   s~_i   = -F_i * 2^-47,  |s~_i - s_i| <= L*2^-48 + L*|s_i|*2^-53      (L = row length; table rounding + the
+//                                                   rounding of the canonical fp64 chain + one conversion)
+// P_i = exp(s~_i) and log1p(-P_i) go into the sums for every row whose keep decision is beyond doubt at that error
+// (F_i + e <= T or F_i - e > T in integers, e = L*(2 + F_i/2^52) covering twice the bound). Rows it cannot decide,
+// rows whose |s~| is so large that the bound exceeds 5e-13, and the argmax contenders (F_i - e <= the smallest
+// F_j + e seen) go into the slab's candidate list with flag bits; k_fr_refine<true> recomputes exactly those in CSR
+// order: the integer outputs are the canonical ones, bit for bit.
+constexpr uint64_t kFxClamp = 1ULL << 56;
+constexpr double kFxScale = 0x1.0p47;
+
+__global__ __launch_bounds__(256) void k_fx_table(const double* __restrict__ logp, int32_t n_events, uint64_t* __restrict__ fx) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_events) return;
+    const double v = -logp[j] * kFxScale; // >= 0, +inf for p = 0
+    fx[j] = v >= 0x1.0p56 ? kFxClamp : (uint64_t)__double2ll_rn(v);
+}
+
+struct FxAcc { CSum rare, l1p; double n_kept, n_certain; };
+
+struct FxScalars {
+    int64_t total_chunks, n_rows, n_slabs;
+    long long t_keep;   // F + e <= t_keep  => s_i >= log(cut_off) beyond doubt
+    long long t_drop;   // F - e >  t_drop  => s_i <  log(cut_off) beyond doubt
+    long long f_smax;   // F > f_smax: the sum's own error bound exceeds the budget (or an entry was clamped) -> exact pass
+    int32_t L;          // max_row_len (bounded by limit_order when that is smaller)
+    int32_t limit_order, need_len;
+};
+
+template <int SLAB_ROWS, int WAVES, int U, bool TABLE_LDS>
+__global__ __launch_bounds__(WAVES * kWave) void k_fx_sum(const uint4* __restrict__ stream, const int64_t* __restrict__ fr_off,
+                                                          const uint64_t* __restrict__ fx, int32_t n_events,
+                                                          const int64_t* __restrict__ row_ptr, FxScalars sc,
+                                                          double* __restrict__ block_partials, uint16_t* __restrict__ cand_list,
+                                                          unsigned* __restrict__ cand_cnt, unsigned long long* __restrict__ cand_count,
+                                                          uint64_t* __restrict__ keep_mask) {
+    constexpr int kRowBits = SLAB_ROWS > 8192 ? 15 : 14, kThreads = WAVES * kWave, NI = SLAB_ROWS / kThreads;
+    constexpr uint32_t kRowMask = (1u << kRowBits) - 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* sums = reinterpret_cast<unsigned long long*>(smem);                 // [SLAB_ROWS + 64]
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(smem + (size_t)(SLAB_ROWS + 64) * 8);     // [SLAB_ROWS / 64]
+    unsigned long long* s_min = reinterpret_cast<unsigned long long*>(smem + (size_t)(SLAB_ROWS + 64) * 8 + (SLAB_ROWS / 64) * 4);
+    const unsigned long long* tab = s_min + 2;                                              // [n_events] when TABLE_LDS
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int64_t G = (int64_t)gridDim.x;
+    uint4 q[U];
+#define FX_FIRST_CHUNKS(SLAB)                                                                       \
+    if ((SLAB) < sc.n_slabs) {                                                                      \
+        const int64_t f0 = fr_uload(fr_off + (SLAB)), f1 = fr_uload(fr_off + (SLAB) + 1);           \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                             \
+            const int64_t c = f0 + wave + (int64_t)u * WAVES;                                       \
+            q[u] = stream[(c < f1 ? c : sc.total_chunks) * kWave + lane];                           \
+        }                                                                                           \
+    }
+    FX_FIRST_CHUNKS((int64_t)blockIdx.x)
+    for (int i = tid; i < SLAB_ROWS + 64; i += kThreads) sums[i] = 0ULL;
+    if (tid == 0) s_min[0] = ~0ULL;
+    if (TABLE_LDS) {
+        unsigned long long* t = const_cast<unsigned long long*>(tab);
+        for (int i = tid; i < n_events; i += kThreads) t[i] = fx[i];
+    }
+    fr_barrier();
+
+    FxAcc acc = {{0.0, 0.0}, {0.0, 0.0}, 0.0, 0.0};
+    unsigned long long n_cand = 0;
+    for (int64_t s = (int64_t)blockIdx.x; s < sc.n_slabs; s += G) {
+        const int64_t c0 = fr_uload(fr_off + s), c1 = fr_uload(fr_off + s + 1);
+        // -------- phase 1: any wave, any chunk: table value, unordered exact LDS add
+        for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * WAVES) {
+            unsigned long long v[U][4];
+            if (!TABLE_LDS) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[u][k] = fx[e[k] >> kRowBits];
+                }
+            }
+            uint4 qn[U]; // next step's chunks: issued behind the gathers, so the adds do not wait for them
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t c = cb + (int64_t)(U + u) * WAVES;
+                qn[u] = stream[(c < c1 ? c : sc.total_chunks) * kWave + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                if (TABLE_LDS) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[u][k] = tab[e[k] >> kRowBits];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    __hip_atomic_fetch_add(&sums[e[k] & kRowMask], v[u][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) q[u] = qn[u];
+        }
+        FX_FIRST_CHUNKS(s + G) // the next slab's stream starts under this slab's end step
+        fr_barrier();
+        // -------- phase 2: classify, fold the decided rows, list the others
+        const int64_t r0 = s * SLAB_ROWS;
+        const unsigned long long m_run = s_min[0]; // smallest F + e of a decided kept row in this workgroup's earlier slabs
+        // (a) the best decided row of this wave: only the keep rule, no state kept (the sums are read again below)
+        unsigned long long my_min = ~0ULL;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const unsigned long long Fi = sums[i * kThreads + tid];
+            const int64_t r = r0 + i * kThreads + tid;
+            bool ok = r < sc.n_rows;
+            if (sc.need_len && ok) ok = (int)(row_ptr[r + 1] - row_ptr[r]) <= sc.limit_order;
+            const unsigned long long e = (unsigned long long)sc.L * (2ULL + (Fi >> 52));
+            ok = ok && (long long)(Fi + e) <= sc.t_keep && (long long)Fi <= sc.f_smax;
+            if (ok) my_min = Fi + e < my_min ? Fi + e : my_min;
+        }
+        unsigned long long w_min = my_min;
+#pragma unroll
+        for (int d = kWave / 2; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(w_min, d, kWave);
+            w_min = o < w_min ? o : w_min;
+        }
+        // argmax contenders: anything that may still beat the best decided row seen so far (this wave's included)
+        const unsigned long long bar = w_min < m_run ? w_min : m_run;
+        if (lane == 0 && w_min != ~0ULL)
+            __hip_atomic_fetch_min(&s_min[0], w_min, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (b) four rows at a time: classification, flag bits (two per row, packed), ballots, the decided rows' exp / log1p
+        unsigned flpack = 0u;
+        constexpr int FOLD = WAVES > 8 ? 2 : 4; // independent exp chains per lane: four waves per SIMD hide the rest
+#pragma unroll 1 // ONE copy of the exp / log1p code (unrolled, the kernel is 9000 instructions and spills)
+        for (int i0 = 0; i0 < NI; i0 += FOLD) {
+            double sv[FOLD];
+            bool on[FOLD];
+#pragma unroll
+            for (int u = 0; u < FOLD; ++u) {
+                const int i = i0 + u;
+                const int rl = i * kThreads + tid;
+                const unsigned long long Fi = sums[rl];
+                sums[rl] = 0ULL;
+                const int64_t r = r0 + rl;
+                const bool valid = r < sc.n_rows;
+                bool len_ok = true;
+                if (sc.need_len && valid) len_ok = (int)(row_ptr[r + 1] - row_ptr[r]) <= sc.limit_order;
+                const unsigned long long e = (unsigned long long)sc.L * (2ULL + (Fi >> 52));
+                const bool big = (long long)Fi > sc.f_smax;
+                const bool kc = (long long)(Fi + e) <= sc.t_keep;
+                const bool dc = Fi < kFxClamp && (long long)Fi - (long long)e > sc.t_drop;
+                const bool kept = valid && len_ok && kc && !big;
+                const bool listed = valid && len_ok && !dc && (big || !kc); // bit 15: left to the exact pass
+                const bool contend = (kept || listed) && (big || bar == ~0ULL || Fi <= bar + e); // F - e <= bar
+                flpack |= ((listed ? 2u : 0u) | (contend ? 1u : 0u)) << (2 * i);
+                const unsigned long long mi = __ballot(listed || contend);
+                if (lane == 0) s_cnt[i * WAVES + wave] = (unsigned)__builtin_popcountll(mi);
+                if (keep_mask != nullptr) {
+                    const unsigned long long km = __ballot(kept);
+                    const int64_t rw = r0 + i * kThreads + wave * kWave;
+                    if (lane == 0 && rw < sc.n_rows) keep_mask[rw >> 6] = km; // the exact pass ORs its rows in afterwards
+                }
+                on[u] = kept;
+                sv[u] = -((double)Fi * 0x1.0p-47);
+            }
+            fold_kept_rows<FOLD>(acc.rare, acc.l1p, acc.n_certain, sv, on);
+#pragma unroll
+            for (int u = 0; u < FOLD; ++u) acc.n_kept += on[u] ? 1.0 : 0.0;
+        }
+        if (tid < 64) sums[SLAB_ROWS + tid] = 0ULL; // the sink
+        unsigned long long m[NI];
+        unsigned fl[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            fl[i] = ((flpack >> (2 * i)) & 3u) << 14;
+            m[i] = __ballot(fl[i] != 0u);
+        }
+        fr_barrier();
+        const unsigned total = fr_emit_candidates<NI, WAVES>(m, fl, s_cnt, lane, wave, tid, cand_list + s * SLAB_ROWS);
+        if (tid == 0) cand_cnt[s] = total;
+        n_cand += total; // workgroup-uniform
+    }
+#undef FX_FIRST_CHUNKS
+    if (tid == 0 && n_cand) atomicAdd(cand_count, n_cand);
+
+    __syncthreads(); // the sums are dead: the workgroup's record
+    double* s_red = reinterpret_cast<double*>(smem);
+    Acc full;
+    acc_init(full); // no max / argmax from this pass: they come from the exact pass over the contenders
+    full.rare = acc.rare; full.l1p = acc.l1p; full.n_kept = acc.n_kept; full.n_certain = acc.n_certain;
+    acc_wave_reduce(full);
+    if (lane == 0) acc_store(s_red + wave * kAccDoubles, full);
+    __syncthreads();
+    if (tid == 0) {
+        Acc t;
+        acc_load(t, s_red);
+        for (int w = 1; w < WAVES; ++w) {
+            Acc o;
+            acc_load(o, s_red + w * kAccDoubles);
+            acc_merge(t, o);
+        }
+        acc_store(block_partials + (size_t)blockIdx.x * kAccDoubles, t);
     }
 }
 
@@ -579,10 +799,106 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
 }
 
 hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, const unsigned* cand_cnt, int slab_rows,
-                            int64_t n_slabs, uint64_t* keep_mask, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(k_fr_refine, dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows, n_slabs,
-                       keep_mask);
+                            int64_t n_slabs, uint64_t* keep_mask, int grid, bool flagged, int part_offset, hipStream_t s) {
+    if (flagged)
+        hipLaunchKernelGGL(k_fr_refine<true>, dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows,
+                           n_slabs, keep_mask, part_offset);
+    else
+        hipLaunchKernelGGL(k_fr_refine<false>, dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows,
+                           n_slabs, keep_mask, part_offset);
     return hipGetLastError();
+}
+
+// ---- fixed-point sum pass -------------------------------------------------------------------------------------
+int fx_max_row_len() { return 63; } // 63 entries of at most 2^56 stay below 2^62
+size_t fx_table_lds_max_events(int slab_rows) { // the u64 table beside the row sums of one workgroup
+    const size_t per_wg = (size_t)160 * 1024;
+    const size_t fixed = (size_t)(slab_rows + 64) * 8 + (size_t)(slab_rows / 64) * 4 + 16 + 64;
+    return per_wg > fixed ? (per_wg - fixed) / 8 : 0;
+}
+
+hipError_t launch_fx_table(const double* logp, int32_t n_events, uint64_t* fx, hipStream_t s) {
+    if (n_events <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fx_table, dim3(grid_for(n_events, 256)), dim3(256), 0, s, logp, n_events, fx);
+    return hipGetLastError();
+}
+
+namespace {
+size_t fx_lds_bytes(int32_t n_events, int slab_rows, bool* tab_lds) {
+    static const bool no_lds = getenv("CANOPY_FX_NOLDS") != nullptr; // tuning only
+    *tab_lds = !no_lds && (size_t)n_events <= fx_table_lds_max_events(slab_rows);
+    return (size_t)(slab_rows + 64) * 8 + (size_t)(slab_rows / 64) * 4 + 16 + (*tab_lds ? (size_t)n_events * 8 : 0);
+}
+} // namespace
+
+int fx_sum_grid(int n_cu, int32_t n_events, int64_t n_slabs) {
+    bool tab_lds = false;
+    const size_t lds = fx_lds_bytes(n_events, fr_slab_rows_for(n_events), &tab_lds);
+    const int per_cu = lds <= (size_t)80 * 1024 ? 2 : 1; // two workgroups per CU while their LDS fits
+    int64_t g = (int64_t)n_cu * per_cu;
+    if (g > n_slabs) g = n_slabs;
+    return g < 1 ? 1 : (int)g;
+}
+
+namespace {
+template <int SLAB_ROWS, int WAVES, int U, bool TABLE_LDS>
+hipError_t launch_fx_t(const uint32_t* stream, const int64_t* fr_off, const uint64_t* fx, int32_t n_events, const int64_t* row_ptr,
+                       const FxScalars& sc, double* block_partials, uint16_t* cand_list, unsigned* cand_cnt,
+                       unsigned long long* cand_count, uint64_t* keep_mask, int grid, hipStream_t s) {
+    const void* fn = reinterpret_cast<const void*>(&k_fx_sum<SLAB_ROWS, WAVES, U, TABLE_LDS>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); // per device: every launch
+    if (e != hipSuccess) return e;
+    bool tl = false;
+    const size_t lds = fx_lds_bytes(n_events, SLAB_ROWS, &tl);
+    hipLaunchKernelGGL((k_fx_sum<SLAB_ROWS, WAVES, U, TABLE_LDS>), dim3((unsigned)grid), dim3(WAVES * kWave), lds, s,
+                       reinterpret_cast<const uint4*>(stream), fr_off, fx, n_events, row_ptr, sc, block_partials, cand_list,
+                       cand_cnt, cand_count, keep_mask);
+    return hipGetLastError();
+}
+} // namespace
+
+// One pass A launch. log_cut = -inf for cut_off = 0. The caller runs launch_fr_refine(flagged = true) behind it.
+hipError_t launch_fx_sum(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const uint64_t* fx,
+                         const int64_t* row_ptr, int64_t n_rows, int32_t n_events, int64_t n_slabs, double log_cut,
+                         int32_t limit_order, int32_t max_row_len, double* block_partials, uint16_t* cand_list,
+                         unsigned* cand_cnt, unsigned long long* cand_count, uint64_t* keep_mask, int grid, hipStream_t s) {
+    FxScalars sc;
+    sc.total_chunks = total_chunks; sc.n_rows = n_rows; sc.n_slabs = n_slabs;
+    sc.limit_order = limit_order;
+    sc.need_len = (limit_order != 0 && limit_order < max_row_len) ? 1 : 0;
+    int L = max_row_len;
+    if (limit_order != 0 && limit_order < L) L = limit_order; // longer rows are dropped by the exact length rule
+    if (L < 1) L = 1;
+    sc.L = L;
+    // |s~ - s| <= L*2^-48 + L*|s|*2^-53 must stay below 5e-13 for a row to be summed from s~
+    const double smax = (5e-13 - (double)L * 0x1.0p-48) / ((double)L * 0x1.0p-53);
+    const double fs = smax * kFxScale;
+    sc.f_smax = fs >= (double)(kFxClamp - 1) ? (long long)(kFxClamp - 1) : (fs < 0.0 ? -1 : (long long)fs);
+    const long long kAll = (long long)1 << 62; // cut_off = 0: every F (< 2^62) is kept beyond doubt
+    if (log_cut == -INFINITY) { sc.t_keep = kAll; sc.t_drop = kAll; }
+    else {
+        const double t = -log_cut * kFxScale; // the cut-off in fixed point; may be negative (cut_off > 1)
+        const double lo = floor(t) - 2.0, hi = ceil(t) + 2.0;
+        sc.t_keep = lo < -0x1.0p62 ? -kAll : (lo > 0x1.0p62 ? kAll : (long long)lo);
+        sc.t_drop = hi < -0x1.0p62 ? -kAll : (hi > 0x1.0p62 ? kAll : (long long)hi);
+    }
+    static const int u_env = getenv("CANOPY_FX_U") ? atoi(getenv("CANOPY_FX_U")) : 0;  // tuning only
+    static const int w_env = getenv("CANOPY_FX_W") ? atoi(getenv("CANOPY_FX_W")) : 0;  // tuning only (waves per workgroup)
+    const int slab_rows = fr_slab_rows_for(n_events);
+    bool tab_lds = false;
+    (void)fx_lds_bytes(n_events, slab_rows, &tab_lds);
+#define FX_GO(SR, W, UU, TL) return launch_fx_t<SR, W, UU, TL>(stream, fr_off, fx, n_events, row_ptr, sc, block_partials, cand_list, cand_cnt, cand_count, keep_mask, grid, s)
+    if (slab_rows > 8192) {
+        if (tab_lds) FX_GO(16384, 16, 2, true);
+        if (u_env == 4) FX_GO(16384, 16, 4, false);
+        FX_GO(16384, 16, 2, false);
+    }
+    if (tab_lds) { if (w_env == 8) FX_GO(8192, 8, 2, true); FX_GO(8192, 16, 2, true); }
+    if (w_env == 8) { if (u_env == 4) FX_GO(8192, 8, 4, false); FX_GO(8192, 8, 2, false); }
+    if (u_env == 4) FX_GO(8192, 16, 4, false);
+    if (u_env == 1) FX_GO(8192, 16, 1, false);
+    FX_GO(8192, 16, 2, false);
+#undef FX_GO
 }
 
 } // namespace canopy

@@ -242,6 +242,12 @@ class Comm:
         capi.check(capi.lib().canopy_comm_fetch(self._h, 0, None, parts), "canopy_comm_fetch", self._ctx.handle)
         return list(parts)
 
+    def last_collective_ms(self):
+        ms = C.c_double()
+        capi.check(capi.lib().canopy_comm_last_collective_ms(self._h, C.byref(ms)), "canopy_comm_last_collective_ms",
+                   self._ctx.handle)
+        return ms.value
+
     def mc_fetch(self):
         res = capi.McResult()
         capi.check(capi.lib().canopy_comm_mc_fetch(self._h, C.byref(res)), "canopy_comm_mc_fetch", self._ctx.handle)

@@ -195,9 +195,15 @@ enum {
                                       LDS (large E); built once by canopy_model_prepare */
     CANOPY_KERNEL_VALUE_SCATTER = 4, /* derived layout: per-slab column-ordered entry stream, gathered
                                         values scattered to CSR slots in LDS, lane-per-row sums (large E) */
-    CANOPY_KERNEL_FILTER_REFINE = 5 /* cut_off > 0, no per-row output: a fast unordered pass flags the rows
+    CANOPY_KERNEL_FILTER_REFINE = 5, /* cut_off > 0, no per-row output: a fast unordered pass flags the rows
                                        that might survive, an exact CSR-order pass recomputes only those.
                                        Reported values are exactly those of the other variants. */
+    CANOPY_KERNEL_FIXED_SUM = 6     /* no per-row output, rows of <= 63 entries: every row summed in 2^-47 fixed point
+                                       (integer adds commute, so all waves share a slab: no ordering constraint),
+                                       exp / log1p taken from that sum (|error| <= L*2^-48 + L*|s|*2^-53, inside the
+                                       1e-12 contract); the rows whose keep decision or argmax rank that error could
+                                       change are recomputed in exact CSR order. Integer outputs are the canonical ones
+                                       bit for bit; AUTO's choice for cut_off = 0 and for cut-offs most rows survive. */
 };
 
 CANOPY_API void canopy_quant_params_default(canopy_quant_params* params);
@@ -274,6 +280,11 @@ CANOPY_API canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* dev
  * Monte-Carlo (K6): with a communicator attached (process-per-GPU shape) canopy_mc_run_async also sums
  * {hits, trials} over the ranks (one u64 all-reduce); canopy_comm_mc_fetch returns the global estimate.
  * canopy_comm_free detaches (the context returns to single-shard behaviour); free it before its context.
+ * Streams: the all-reduce is enqueued on the communicator's OWN stream behind an event of the pass's final reduce,
+ * into one of two alternating slot buffers, so the context's stream starts the next pass while the (latency-bound)
+ * collective of this one is still in flight. canopy_comm_fetch waits for the collective of the LAST enqueued pass;
+ * canopy_ctx_synchronize waits for the kernels only. CANOPY_COMM_SERIAL=1 in the environment puts the collective back
+ * on the context's stream (A/B measurements).
  */
 #define CANOPY_COMM_ID_BYTES 128
 typedef struct canopy_comm_id { char bytes[CANOPY_COMM_ID_BYTES]; } canopy_comm_id;
@@ -298,6 +309,9 @@ CANOPY_API canopy_status canopy_combine_partials(const canopy_partial* parts, in
    parts[world_size] may be NULL. flags: CANOPY_QUANT_CLAMP. */
 CANOPY_API canopy_status canopy_comm_fetch(canopy_comm* comm, uint32_t flags, canopy_quant_result* result,
                                            canopy_partial* parts);
+
+/* Device time of the last pass's all-reduce (event pair around it on the stream it ran on; waits for it). */
+CANOPY_API canopy_status canopy_comm_last_collective_ms(canopy_comm* comm, double* ms);
 
 /* Optional per-row outputs of the last pass that requested them (host destination). */
 CANOPY_API canopy_status canopy_fetch_row_logp(canopy_ctx* ctx, const canopy_model* model,

@@ -76,11 +76,14 @@ def test_random_models_every_variant(gpu_ctx, oracle, seed):
         agree(got, want)
         assert np.array_equal(gpu_ctx.fetch_row_logp(model), want.row_logp), kern
         assert np.array_equal(gpu_ctx.fetch_keep_mask(model), want.keep_mask), kern
-    if cut_off > 0:
-        got = gpu_ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order, kernel=_capi.KERNEL_FILTER_REFINE,
+    sum_only = [_capi.KERNEL_FILTER_REFINE] if cut_off > 0 else []
+    if max_len <= 63:
+        sum_only.append(_capi.KERNEL_FIXED_SUM)  # any cut-off, 0 included
+    for kern in sum_only:
+        got = gpu_ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order, kernel=kern,
                                                      flags=_capi.QUANT_KEEP_MASK))
         agree(got, want)
-        assert np.array_equal(gpu_ctx.fetch_keep_mask(model), want.keep_mask)
+        assert np.array_equal(gpu_ctx.fetch_keep_mask(model), want.keep_mask), kern
     # importance contributions behind AUTO
     gpu_ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order, flags=_capi.QUANT_IMPORTANCE))
     contrib = gpu_ctx.fetch_importance(model)

@@ -36,6 +36,8 @@ def variants(n_events, max_row_len=10, cut_off=0.0):
         v.append(_capi.KERNEL_VALUE_SCATTER)
     if 1 <= n_events <= (1 << 18) and cut_off > 0:
         v.append(_capi.KERNEL_FILTER_REFINE)  # sum-only variant (no per-row output)
+    if 1 <= n_events <= (1 << 18) and max_row_len <= 63:
+        v.append(_capi.KERNEL_FIXED_SUM)  # sum-only variant, any cut-off
     return v
 
 
@@ -47,7 +49,7 @@ def check_against_oracle(ctx, oracle, row_ptr, col, p, n_events, cut_off, limit_
     model.set_probabilities(p)
     max_len = int(np.diff(row_ptr).max()) if len(row_ptr) > 1 else 0
     for kern in variants(n_events, max_len, cut_off):
-        if kern == _capi.KERNEL_FILTER_REFINE:
+        if kern in (_capi.KERNEL_FILTER_REFINE, _capi.KERNEL_FIXED_SUM):
             got = ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order,
                                                      flags=_capi.QUANT_KEEP_MASK, kernel=kern))
             assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row), kern
@@ -364,3 +366,47 @@ def test_captured_pass_replays_like_an_eager_one(gpu_ctx, oracle):
         finally:
             gpu_ctx.graph_free(g)
             model.close()
+
+
+def test_fixed_sum_decides_integers_exactly(gpu_ctx, oracle):
+    """FIXED_SUM sums every row in 2^-47 fixed point and recomputes in exact CSR order only the rows that error could
+    decide differently. Adversarial for it: rows sitting exactly on / one ulp around the cut-off, many rows tied for
+    the argmax (ties -> lowest row), events with p = 0 (clamped table entries), p = 1, p so small that |s| passes the
+    accuracy budget, and a limit_order below the longest row."""
+    from canopy_amd import _capi, default_params
+    rng = np.random.default_rng(77)
+    n_events, n_rows = 3000, 40_000
+    p = 10.0 ** rng.uniform(-6, -0.5, size=n_events)
+    p[0], p[1], p[2], p[3] = 0.0, 1.0, 1e-200, 5e-324
+    best = [int(np.argmax(p[4:])) + 4]
+    rows = []
+    for i in range(n_rows):
+        if 20_000 <= i < 20_500:
+            rows.append(best)  # the global maximum, tied 500 times (ties resolve to the lowest row)
+            continue
+        r = np.sort(rng.choice(np.arange(4, n_events), size=int(rng.integers(1, 9)), replace=False)).tolist()
+        if i % 97 == 0:
+            r = [i // 97 % 4] + r  # the special events (smallest ids: the row stays ascending)
+        rows.append(r)
+    row_ptr, col = csr(rows)
+    full = oracle.quantify(row_ptr, col, p, cut_off=0.0, limit_order=0, n_threads=4)
+    assert int(full.argmax_row) <= 20_000 and full.max_logp == np.log(p[best[0]])
+    finite = full.row_logp[np.isfinite(full.row_logp)]
+    pivots = [float(np.exp(x)) for x in np.quantile(finite, [0.3, 0.6, 0.9])]
+    pivots += [float(np.nextafter(pv, 0.0)) for pv in pivots[:2]] + [float(np.nextafter(pivots[0], 1.0))]
+    model = gpu_ctx.upload(row_ptr, col, n_events)
+    model.set_probabilities(p)
+    for cut in [0.0, 1e-300] + pivots:
+        for lim in (0, 3, 20):
+            want = oracle.quantify(row_ptr, col, p, cut_off=cut, limit_order=lim, n_threads=4)
+            got = gpu_ctx.quantify(model, default_params(cut_off=cut, limit_order=lim, kernel=_capi.KERNEL_FIXED_SUM,
+                                                         flags=_capi.QUANT_KEEP_MASK))
+            assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row), (cut, lim)
+            if want.n_kept and want.argmax_row >= 0:
+                assert got.max_logp == want.max_logp, (cut, lim)
+            assert np.array_equal(gpu_ctx.fetch_keep_mask(model), want.keep_mask), (cut, lim)
+            if want.rare_event > 0:
+                assert rel(got.rare_event, want.rare_event) < TOL and rel(got.mcub, want.mcub) < TOL, (cut, lim)
+            else:
+                assert got.rare_event == want.rare_event and got.mcub == want.mcub
+    model.close()
