@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round-2 A/B runs on the GPU box (via gpurun): usage bash benchmarks/r2_ab.sh <tag>
+set -u
+TAG=${1:-ab}
+O=gpurun_out
+mkdir -p $O
+run() { # name, env..., -- args
+  local name=$1; shift
+  local envs=()
+  while [ "$1" != "--" ]; do envs+=("$1"); shift; done
+  shift
+  env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
+}
+run fx_default X=1 -- --cut-off 0 --no-also --steps 30 --warmup 5
+run fx_add14 CANOPY_FX_ADD=14 -- --cut-off 0 --no-also --steps 30 --warmup 5
+run fx_add8u4 CANOPY_FX_ADD=8 CANOPY_FX_U=4 -- --cut-off 0 --no-also --steps 30 --warmup 5
+run fx_u4 CANOPY_FX_U=4 -- --cut-off 0 --no-also --steps 30 --warmup 5
+run fx_e10k X=1 -- --cut-off 0 --kernel 6 --no-also --steps 30 --warmup 5 --events 10000
+run head X=1 -- --no-also
+run head_e2e5 X=1 -- --no-also --events 200000 --steps 50
+run fx_e2e5 X=1 -- --no-also --events 200000 --steps 30 --cut-off 0
+python - <<'PY'
+import json,glob,os
+for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):
+    try:
+        j=json.load(open(f)); r=j["roofline"]
+        print(os.path.basename(f), "ms/step %.4f k_ms %.4f/%.4f pass %.4f frac %.3f kern %d" % (j["ms_per_step"], r["avg_kernel_ms"], r["min_kernel_ms"], r["avg_pass_ms"], r["frac"], j["config"]["kernel_ran"]), j["result"]["n_kept"], j["result"]["rare_event"], r.get("last_collective_ms"))
+    except Exception as e:
+        print(f, "ERR", e)
+PY

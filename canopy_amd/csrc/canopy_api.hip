@@ -607,11 +607,12 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             HIP_TRY(ctx, hipMalloc(&ctx->d_fr_list, sizeof(uint16_t) * (size_t)(list_len > 0 ? list_len : 1)));
             ctx->fr_list_cap = list_len; ++ctx->scratch_gen;
         }
-        if (ctx->fr_cnt_cap < m->n_fr_slabs || !ctx->d_fr_cnt) {
+        const int64_t cnt_need = m->n_fr_slabs * 8; // the fixed-point pass keeps up to eight list units per slab
+        if (ctx->fr_cnt_cap < cnt_need || !ctx->d_fr_cnt) {
             if (ctx->d_fr_cnt) (void)hipFree(ctx->d_fr_cnt);
             ctx->d_fr_cnt = nullptr; ctx->fr_cnt_cap = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->d_fr_cnt, sizeof(unsigned) * (size_t)(m->n_fr_slabs > 0 ? m->n_fr_slabs : 1)));
-            ctx->fr_cnt_cap = m->n_fr_slabs; ++ctx->scratch_gen;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_fr_cnt, sizeof(unsigned) * (size_t)(cnt_need > 0 ? cnt_need : 1)));
+            ctx->fr_cnt_cap = cnt_need; ++ctx->scratch_gen;
         }
         if (want_mask && variant == CANOPY_KERNEL_FILTER_REFINE) // the refine pass ORs the exact keep bits into a cleared mask
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
@@ -642,7 +643,9 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         HIP_TRY(ctx, launch_fr_filter(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, m->n_rows,
                                       m->n_events, m->n_fr_slabs, cand_cut, ctx->d_fr_list, ctx->d_fr_cnt, ctx->d_fr_count, ctx->n_cu,
                                       ctx->stream));
-        HIP_TRY(ctx, launch_fr_refine(a, ctx->d_fr_list, ctx->d_fr_cnt, slab_rows, m->n_fr_slabs,
+        int unit_rows = slab_rows, units_per_slab = 1; // list units the exact pass walks
+        if (variant == CANOPY_KERNEL_FIXED_SUM) fx_list_units(m->n_events, &unit_rows, &units_per_slab);
+        HIP_TRY(ctx, launch_fr_refine(a, ctx->d_fr_list, ctx->d_fr_cnt, unit_rows, m->n_fr_slabs * units_per_slab,
                                       want_mask ? ctx->d_keep_mask : nullptr, grid, variant == CANOPY_KERNEL_FIXED_SUM, grid_fx,
                                       ctx->stream));
         n_records = grid + grid_fx;

@@ -246,6 +246,7 @@ hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, c
                             int64_t n_slabs, uint64_t* keep_mask, int grid, bool flagged, int part_offset, hipStream_t s);
 int fx_max_row_len();
 int fx_sum_grid(int n_cu, int32_t n_events, int64_t n_slabs);
+void fx_list_units(int32_t n_events, int* unit_rows, int* units_per_slab);
 hipError_t launch_fx_table(const double* logp, int32_t n_events, uint64_t* fx, hipStream_t s);
 hipError_t launch_fx_sum(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const uint64_t* fx,
                          const int64_t* row_ptr, int64_t n_rows, int32_t n_events, int64_t n_slabs, double log_cut,

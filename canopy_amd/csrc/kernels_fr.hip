@@ -84,6 +84,16 @@ __global__ __launch_bounds__(256) void k_fr_count_chunks(const int64_t* __restri
     chunks[s] = (row_ptr[r1] - row_ptr[r0] + kFrChunk - 1) / kFrChunk;
 }
 
+// Where the entry of sorted position `pos` of a slab goes: inside its 256-entry chunk the order is transposed, so that
+// lane k's 16-byte load brings sorted entries k, 64 + k, 128 + k, 192 + k -- the 64 lanes of ONE table-gather
+// instruction then cover a contiguous quarter of the chunk's column range (a handful of cache lines) instead of a
+// stride-4 sample of all of it. The LDS-table filter does not care; the gathered passes issue 4x fewer line requests
+// per instruction.
+__device__ __forceinline__ unsigned fr_chunk_slot(unsigned pos) {
+    const unsigned p = pos & (kFrChunk - 1);
+    return (pos - p) + ((p & 63u) << 2) + (p >> 6);
+}
+
 __global__ __launch_bounds__(256) void k_fr_build_sorted(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
                                                          int64_t n_rows, int32_t n_events, int slab_rows, int row_bits,
                                                          const int64_t* __restrict__ fr_off, uint32_t* __restrict__ stream) {
@@ -120,11 +130,11 @@ __global__ __launch_bounds__(256) void k_fr_build_sorted(const int64_t* __restri
         for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
             const uint32_t c = (uint32_t)col_idx[k];
             const unsigned pos = atomicAdd(&hist[(unsigned)(((uint64_t)c * nb) / ne) + 1u], 1u);
-            out[pos] = (c << row_bits) | (uint32_t)(r - r0);
+            out[fr_chunk_slot(pos)] = (c << row_bits) | (uint32_t)(r - r0);
         }
     const int64_t nnz = row_ptr[r1] - row_ptr[r0];
     const int64_t padded = (nnz + kFrChunk - 1) / kFrChunk * kFrChunk;
-    for (int64_t i = nnz + tid; i < padded; i += 256) out[i] = (uint32_t)slab_rows; // col 0 -> the sink row
+    for (int64_t i = nnz + tid; i < padded; i += 256) out[fr_chunk_slot((unsigned)i)] = (uint32_t)slab_rows; // col 0 -> the sink row
 }
 
 __global__ __launch_bounds__(256) void k_fr_fill(uint32_t* p, int64_t n, uint32_t v) {
@@ -424,6 +434,8 @@ __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArg
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     Acc acc;
     acc_init(acc);
+    // a "unit" = slab_rows consecutive rows with their own list segment and count (a whole slab for the filters, the
+    // share of one folding wave for k_fx2); two waves per unit
     const int64_t GW = (int64_t)gridDim.x * kRefineWaves;
     for (int64_t u = (int64_t)blockIdx.x * kRefineWaves + wave; u < 2 * n_slabs; u += GW) {
         const int64_t s = u >> 1;
@@ -671,6 +683,270 @@ __global__ __launch_bounds__(WAVES * kWave) void k_fx_sum(const uint4* __restric
     }
 }
 
+
+// ---- the same pass with the two phases overlapped: adding waves and folding waves ------------------------------
+// k_fx_sum runs its phases one after the other (barriers), so the texture path / LDS atomics of phase 1 and the
+// vector ALU of phase 2 (an exp per row) never work at the same time. Here a 16-wave workgroup keeps TWO slabs of
+// row sums in LDS: waves [0, ADD) add slab k into one buffer while waves [ADD, 16) fold slab k-1 out of the other
+// (classification, exp / log1p, candidate lists, keep mask) and clear it; one workgroup barrier per slab.
+// Each folding wave owns a fixed share of the slab's rows and writes its OWN list segment and count (no
+// cross-wave scan): the lists are ordered and deterministic, and k_fr_refine walks them as "units".
+// exp(s~): table-driven (2^(j/64) in LDS, degree-6 polynomial on |r| <= ln2/128), about a third of ocml's exp.
+constexpr int kFx2Slab = 8192, kFx2Waves = 16;
+
+__device__ __forceinline__ double fx_exp_neg(double x, const double* __restrict__ etab) { // x <= 0 (may be -inf)
+    const double kf = __builtin_rint(x * 0x1.71547652b82fep+6); // 64 / ln 2
+    double r = __builtin_fma(kf, -0x1.62e42fefa0000p-7, x);     // ln2/64, high part (trailing zeros: kf * hi is exact)
+    r = __builtin_fma(kf, -0x1.cf79abc9e3b3ap-46, r);           // low part
+    double q = __builtin_fma(r, 0x1.6c16c16c16c17p-10, 0x1.1111111111111p-7); // 1/720, 1/120
+    q = __builtin_fma(q, r, 0x1.5555555555555p-5);  // 1/24
+    q = __builtin_fma(q, r, 0x1.5555555555555p-3);  // 1/6
+    q = __builtin_fma(q, r, 0.5);
+    const double p = __builtin_fma(q * r, r, r);    // r + r^2 * q
+    const int k = (int)kf;                          // |kf| <= 3.1e6 for any finite fixed-point sum
+    const double t = etab[k & 63];
+    return __builtin_ldexp(__builtin_fma(t, p, t), k >> 6);
+}
+
+template <int ADD, int U, bool TABLE_LDS, bool ALLKEPT>
+__global__ __launch_bounds__(kFx2Waves * kWave) void k_fx2(const uint4* __restrict__ stream, const int64_t* __restrict__ fr_off,
+                                                           const uint64_t* __restrict__ fx, int32_t n_events,
+                                                           const int64_t* __restrict__ row_ptr, FxScalars sc,
+                                                           double* __restrict__ block_partials, uint16_t* __restrict__ cand_list,
+                                                           unsigned* __restrict__ cand_cnt, unsigned long long* __restrict__ cand_count,
+                                                           uint64_t* __restrict__ keep_mask) {
+    constexpr int kRowBits = 14, FW = kFx2Waves - ADD, kUnit = kFx2Slab / FW, NIF = kUnit / kWave, kThreads = kFx2Waves * kWave;
+    constexpr uint32_t kRowMask = (1u << kRowBits) - 1;
+    constexpr int kBuf = kFx2Slab + 64; // + the sink slots
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* bufs = reinterpret_cast<unsigned long long*>(smem);      // [2][kBuf]
+    unsigned long long* s_min = bufs + 2 * kBuf;                                 // [0] running min, [1] candidate total
+    double* etab = reinterpret_cast<double*>(s_min + 2);                         // [64] 2^(j/64)
+    const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(etab + 64); // [n_events] when TABLE_LDS
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int64_t G = (int64_t)gridDim.x;
+    const bool adder = wave < ADD;
+    uint4 q[U];
+#define FX2_FIRST_CHUNKS(SLAB)                                                                      \
+    if ((SLAB) < sc.n_slabs) {                                                                      \
+        const int64_t f0 = fr_uload(fr_off + (SLAB)), f1 = fr_uload(fr_off + (SLAB) + 1);           \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                             \
+            const int64_t c = f0 + wave + (int64_t)u * ADD;                                         \
+            q[u] = stream[(c < f1 ? c : sc.total_chunks) * kWave + lane];                           \
+        }                                                                                           \
+    }
+    if (adder) { FX2_FIRST_CHUNKS((int64_t)blockIdx.x) }
+    for (int i = tid; i < 2 * kBuf; i += kThreads) bufs[i] = 0ULL;
+    if (tid == 0) { s_min[0] = ~0ULL; s_min[1] = 0ULL; }
+    if (tid < 64) etab[tid] = exp2((double)tid * 0x1.0p-6);
+    if (TABLE_LDS) {
+        unsigned long long* t = const_cast<unsigned long long*>(tab);
+        for (int i = tid; i < n_events; i += kThreads) t[i] = fx[i];
+    }
+    fr_barrier();
+
+    FxAcc acc = {{0.0, 0.0}, {0.0, 0.0}, 0.0, 0.0};
+    unsigned long long n_cand = 0; // folding waves: wave-uniform
+    int64_t s_prev = -1;
+    int it = 0;
+    for (int64_t s = (int64_t)blockIdx.x;; s += G, ++it) {
+        const bool have = s < sc.n_slabs;
+        if (adder) {
+            if (have) { // -------- add slab s into buffer it & 1: any adding wave, any chunk
+                unsigned long long* sums = bufs + (size_t)(it & 1) * kBuf;
+                const int64_t c0 = fr_uload(fr_off + s), c1 = fr_uload(fr_off + s + 1);
+                for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * ADD) {
+                    unsigned long long v[U][4];
+                    if (!TABLE_LDS) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[u][k] = fx[e[k] >> kRowBits];
+                        }
+                    }
+                    uint4 qn[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int64_t c = cb + (int64_t)(U + u) * ADD;
+                        qn[u] = stream[(c < c1 ? c : sc.total_chunks) * kWave + lane];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                        if (TABLE_LDS) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[u][k] = tab[e[k] >> kRowBits];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            __hip_atomic_fetch_add(&sums[e[k] & kRowMask], v[u][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) q[u] = qn[u];
+                }
+                FX2_FIRST_CHUNKS(s + G)
+            }
+        } else if (s_prev >= 0) { // -------- fold slab s_prev out of the other buffer
+            unsigned long long* sums = bufs + (size_t)((it - 1) & 1) * kBuf;
+            const int fw = wave - ADD;
+            const int64_t r0 = s_prev * kFx2Slab + (int64_t)fw * kUnit; // first row of this wave's unit
+            const int l0 = fw * kUnit;
+            unsigned long long bar = s_min[0];
+            if (bar == ~0ULL) { // nothing decided yet in this workgroup: the wave's own best row sets the bar
+                unsigned long long mm = ~0ULL;
+                for (int i = 0; i < NIF; ++i) {
+                    const unsigned long long Fi = sums[l0 + i * kWave + lane];
+                    const int64_t r = r0 + i * kWave + lane;
+                    bool ok = r < sc.n_rows && (long long)Fi <= sc.f_smax;
+                    if (!ALLKEPT) {
+                        if (sc.need_len && ok) ok = (int)(row_ptr[r + 1] - row_ptr[r]) <= sc.limit_order;
+                        const unsigned long long e = (unsigned long long)sc.L * (2ULL + (Fi >> 52));
+                        ok = ok && (long long)(Fi + e) <= sc.t_keep;
+                    }
+                    if (ok) mm = Fi < mm ? Fi : mm;
+                }
+#pragma unroll
+                for (int d = kWave / 2; d >= 1; d >>= 1) {
+                    const unsigned long long o = __shfl_xor(mm, d, kWave);
+                    mm = o < mm ? o : mm;
+                }
+                bar = mm;
+            }
+            // argmax contenders: F - e <= bar + e'; one uniform slack covers both error terms (e grows with F by < L per 2^52)
+            const unsigned long long thr = bar == ~0ULL ? ~0ULL : bar + 2ULL * (unsigned long long)sc.L * (3ULL + (bar >> 52));
+            uint16_t* seg = cand_list + (s_prev * FW + fw) * (int64_t)kUnit;
+            unsigned n_list = 0;     // wave-uniform
+            unsigned n_kept_w = 0;   // wave-uniform: decided kept rows of this wave in this slab
+            unsigned long long my_min = ~0ULL;
+#pragma unroll 1 // one copy of the exp / log1p code
+            for (int i0 = 0; i0 < NIF; i0 += 4) {
+                unsigned long long Fv[4];
+                bool on[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { // all four LDS reads first
+                    const int rl = l0 + (i0 + u) * kWave + lane;
+                    Fv[u] = sums[rl];
+                    sums[rl] = 0ULL;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u;
+                    const unsigned long long Fi = Fv[u];
+                    const int64_t r = r0 + i * kWave + lane;
+                    const bool valid = r < sc.n_rows;
+                    const bool big = (long long)Fi > sc.f_smax;
+                    bool kept, listed;
+                    if (ALLKEPT) { // cut_off = 0, no length rule: every valid row is kept; only the accuracy budget lists rows
+                        kept = valid && !big;
+                        listed = valid && big;
+                    } else {
+                        bool len_ok = true;
+                        if (sc.need_len && valid) len_ok = (int)(row_ptr[r + 1] - row_ptr[r]) <= sc.limit_order;
+                        const unsigned long long e = (unsigned long long)sc.L * (2ULL + (Fi >> 52));
+                        const bool kc = (long long)(Fi + e) <= sc.t_keep;
+                        const bool dc = Fi < kFxClamp && (long long)Fi - (long long)e > sc.t_drop;
+                        kept = valid && len_ok && kc && !big;
+                        listed = valid && len_ok && !dc && (big || !kc);
+                    }
+                    const bool contend = (kept || listed) && (big || Fi <= thr);
+                    const unsigned long long mi = __ballot(listed || contend);
+                    if (mi != 0ULL) { // wave-uniform; rare
+                        if (listed || contend)
+                            seg[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u))] =
+                                (uint16_t)((listed ? 0x8000u : 0u) | (contend ? 0x4000u : 0u) | (unsigned)(i * kWave + lane));
+                        n_list += (unsigned)__builtin_popcountll(mi);
+                    }
+                    const unsigned long long km = __ballot(kept);
+                    n_kept_w += (unsigned)__builtin_popcountll(km);
+                    if (keep_mask != nullptr) {
+                        const int64_t rw = r0 + i * kWave;
+                        if (lane == 0 && rw < sc.n_rows) keep_mask[rw >> 6] = km; // the exact pass ORs its rows in afterwards
+                    }
+                    if (kept) my_min = Fi < my_min ? Fi : my_min;
+                    on[u] = kept;
+                }
+                // P = exp(s~) for all four rows unconditionally (four independent chains the scheduler interleaves; a
+                // branch per row serialises them), masked afterwards
+                double P[4], l[4];
+                bool any_big = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) P[u] = fx_exp_neg(-((double)Fv[u] * 0x1.0p-47), etab);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    P[u] = on[u] ? P[u] : 0.0;
+                    any_big = any_big || P[u] >= 0x1.0p-12;
+                }
+                if (!__any(any_big)) {
+                    // every P < 2^-12: log1p(-P) = -P(1 + P/2 + P^2/3 + P^3/4 + P^4/5 + P^5/6) to < 1e-19 relative. The four
+                    // terms are added plainly first (positive terms: <= 3 ulp relative), ONE compensated add per batch
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        double t = __builtin_fma(P[u], 1.0 / 6.0, 0.2);
+                        t = __builtin_fma(t, P[u], 0.25);
+                        t = __builtin_fma(t, P[u], 1.0 / 3.0);
+                        t = __builtin_fma(t, P[u], 0.5);
+                        t = __builtin_fma(t, P[u], 1.0);
+                        l[u] = -P[u] * t;
+                    }
+                    csum_add(acc.rare, (P[0] + P[1]) + (P[2] + P[3]));
+                    csum_add(acc.l1p, (l[0] + l[1]) + (l[2] + l[3]));
+                } else { // some lane has a large P (or a certain row, P >= 1): the careful per-row path
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        double lu = log1p_neg_small(P[u]);
+                        if (on[u] && P[u] >= 0x1.0p-12) lu = (P[u] < 1.0) ? log1p(-P[u]) : 0.0;
+                        fold_terms(acc.rare, acc.l1p, acc.n_certain, P[u], lu, on[u]);
+                    }
+                }
+            }
+            if (lane == 0) acc.n_kept += (double)n_kept_w;
+            if (fw == 0) sums[kFx2Slab + lane] = 0ULL; // the sink
+#pragma unroll
+            for (int d = kWave / 2; d >= 1; d >>= 1) {
+                const unsigned long long o = __shfl_xor(my_min, d, kWave);
+                my_min = o < my_min ? o : my_min;
+            }
+            if (lane == 0) {
+                cand_cnt[s_prev * FW + fw] = n_list;
+                if (my_min != ~0ULL) { // F + e of the best decided row
+                    const unsigned long long up = my_min + (unsigned long long)sc.L * (2ULL + (my_min >> 52));
+                    __hip_atomic_fetch_min(&s_min[0], up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            n_cand += n_list;
+        }
+        fr_barrier();
+        if (!have) break;
+        s_prev = s;
+    }
+#undef FX2_FIRST_CHUNKS
+    if (!adder && lane == 0 && n_cand)
+        __hip_atomic_fetch_add(&s_min[1], n_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads(); // the sums are dead: the workgroup's record
+    if (tid == 0 && s_min[1]) atomicAdd(cand_count, s_min[1]); // one global atomic per workgroup
+    double* s_red = reinterpret_cast<double*>(smem);
+    Acc full;
+    acc_init(full); // no max / argmax from this pass: they come from the exact pass over the contenders
+    full.rare = acc.rare; full.l1p = acc.l1p; full.n_kept = acc.n_kept; full.n_certain = acc.n_certain;
+    acc_wave_reduce(full);
+    __syncthreads();
+    if (lane == 0) acc_store(s_red + wave * kAccDoubles, full);
+    __syncthreads();
+    if (tid == 0) {
+        Acc t;
+        acc_load(t, s_red);
+        for (int w = 1; w < kFx2Waves; ++w) {
+            Acc o;
+            acc_load(o, s_red + w * kAccDoubles);
+            acc_merge(t, o);
+        }
+        acc_store(block_partials + (size_t)blockIdx.x * kAccDoubles, t);
+    }
+}
+
 } // namespace
 
 int fr_max_events() { return 1 << 18; }
@@ -831,13 +1107,37 @@ size_t fx_lds_bytes(int32_t n_events, int slab_rows, bool* tab_lds) {
 }
 } // namespace
 
+namespace {
+bool fx_use_overlapped(int32_t n_events) { // k_fx2 needs two 8192-row buffers
+    static const bool old_only = getenv("CANOPY_FX_OLD") != nullptr; // tuning only
+    return !old_only && fr_slab_rows_for(n_events) == 8192;
+}
+constexpr size_t kFx2FixedLds = (size_t)2 * (kFx2Slab + 64) * 8 + 16 + 64 * 8;
+} // namespace
+
 int fx_sum_grid(int n_cu, int32_t n_events, int64_t n_slabs) {
-    bool tab_lds = false;
-    const size_t lds = fx_lds_bytes(n_events, fr_slab_rows_for(n_events), &tab_lds);
-    const int per_cu = lds <= (size_t)80 * 1024 ? 2 : 1; // two workgroups per CU while their LDS fits
+    int per_cu = 1;
+    if (!fx_use_overlapped(n_events)) {
+        bool tab_lds = false;
+        const size_t lds = fx_lds_bytes(n_events, fr_slab_rows_for(n_events), &tab_lds);
+        per_cu = lds <= (size_t)80 * 1024 ? 2 : 1; // two workgroups per CU while their LDS fits
+    }
     int64_t g = (int64_t)n_cu * per_cu;
     if (g > n_slabs) g = n_slabs;
     return g < 1 ? 1 : (int)g;
+}
+
+// rows per candidate-list unit and units per slab of the pass launch_fx_sum will run for this model
+void fx_list_units(int32_t n_events, int* unit_rows, int* units_per_slab) {
+    if (fx_use_overlapped(n_events)) {
+        static const int add_env = getenv("CANOPY_FX_ADD") ? atoi(getenv("CANOPY_FX_ADD")) : 0; // tuning only
+        const int fw = add_env == 14 ? 2 : (add_env == 8 ? 8 : 4);
+        *unit_rows = kFx2Slab / fw;
+        *units_per_slab = fw;
+    } else {
+        *unit_rows = fr_slab_rows_for(n_events);
+        *units_per_slab = 1;
+    }
 }
 
 namespace {
@@ -885,6 +1185,35 @@ hipError_t launch_fx_sum(const uint32_t* stream, const int64_t* fr_off, int64_t 
     static const int u_env = getenv("CANOPY_FX_U") ? atoi(getenv("CANOPY_FX_U")) : 0;  // tuning only
     static const int w_env = getenv("CANOPY_FX_W") ? atoi(getenv("CANOPY_FX_W")) : 0;  // tuning only (waves per workgroup)
     const int slab_rows = fr_slab_rows_for(n_events);
+    if (fx_use_overlapped(n_events)) { // adding and folding waves side by side
+        static const int add_env = getenv("CANOPY_FX_ADD") ? atoi(getenv("CANOPY_FX_ADD")) : 0; // tuning only
+        const bool tl = kFx2FixedLds + (size_t)n_events * 8 + 64 <= (size_t)160 * 1024 && !getenv("CANOPY_FX_NOLDS");
+        const bool allkept = log_cut == -INFINITY && !sc.need_len;
+        const size_t lds = kFx2FixedLds + (tl ? (size_t)n_events * 8 : 0);
+#define FX2_GO(AD, UU, TL, AK)                                                                                          \
+        do {                                                                                                            \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fx2<AD, UU, TL, AK>),                   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+            if (e_ != hipSuccess) return e_;                                                                            \
+            hipLaunchKernelGGL((k_fx2<AD, UU, TL, AK>), dim3((unsigned)grid), dim3(kFx2Waves * kWave), lds, s,          \
+                               reinterpret_cast<const uint4*>(stream), fr_off, fx, n_events, row_ptr, sc, block_partials, \
+                               cand_list, cand_cnt, cand_count, keep_mask);                                             \
+            return hipGetLastError();                                                                                   \
+        } while (0)
+        if (tl) { if (allkept) FX2_GO(12, 2, true, true); FX2_GO(12, 2, true, false); }
+        if (add_env == 14) {
+            if (u_env == 4) { if (allkept) FX2_GO(14, 4, false, true); FX2_GO(14, 4, false, false); }
+            if (allkept) FX2_GO(14, 2, false, true); FX2_GO(14, 2, false, false);
+        }
+        if (add_env == 8) {
+            if (u_env == 4) { if (allkept) FX2_GO(8, 4, false, true); FX2_GO(8, 4, false, false); }
+            if (allkept) FX2_GO(8, 2, false, true); FX2_GO(8, 2, false, false);
+        }
+        if (u_env == 2) { if (allkept) FX2_GO(12, 2, false, true); FX2_GO(12, 2, false, false); }
+        if (allkept) FX2_GO(12, 4, false, true); // measured at config 3, cut_off 0: 0.889 ms (U = 2: 0.947, 14 adders: 0.97)
+        FX2_GO(12, 4, false, false);
+#undef FX2_GO
+    }
     bool tab_lds = false;
     (void)fx_lds_bytes(n_events, slab_rows, &tab_lds);
 #define FX_GO(SR, W, UU, TL) return launch_fx_t<SR, W, UU, TL>(stream, fr_off, fx, n_events, row_ptr, sc, block_partials, cand_list, cand_cnt, cand_count, keep_mask, grid, s)

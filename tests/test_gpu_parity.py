@@ -283,7 +283,7 @@ def test_gather_slot_buffer_single_rank(gpu_ctx, oracle):
 
 def test_auto_leaves_filter_refine_when_most_rows_survive(gpu_ctx, oracle):
     """AUTO feedback: with a cut-off that keeps most rows the filter flags > 20 % of them; the next AUTO
-    pass on that model runs the wave-slab stream instead. Results are the oracle's either way."""
+    pass on that model runs the all-rows fixed-point pass instead. Results are the oracle's either way."""
     from canopy_amd import _capi, default_params
     n_events, n_rows = 5000, 1_200_000  # AUTO considers filter/refine from 1e6 rows on
     row_ptr, col = oracle.synth_csr(SEED, n_rows, n_events, 4, n_threads=4)
@@ -299,7 +299,8 @@ def test_auto_leaves_filter_refine_when_most_rows_survive(gpu_ctx, oracle):
         assert rel(got.rare_event, want.rare_event) < TOL and rel(got.mcub, want.mcub) < TOL
         ran.append(gpu_ctx.last_kernel_variant())
     # first call: filter + a refine pass over nearly every row; its candidate count then steers AUTO away
-    assert ran == [_capi.KERNEL_FILTER_REFINE, _capi.KERNEL_WAVE_STREAM, _capi.KERNEL_WAVE_STREAM]
+    # (to the fixed-point all-rows pass: no per-row output was asked for)
+    assert ran == [_capi.KERNEL_FILTER_REFINE, _capi.KERNEL_FIXED_SUM, _capi.KERNEL_FIXED_SUM]
     # with the default cut-off few rows survive and AUTO stays with filter/refine
     for _ in range(2):
         gpu_ctx.quantify(model, default_params())
