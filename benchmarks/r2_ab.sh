@@ -11,14 +11,10 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run fx_default X=1 -- --cut-off 0 --no-also --steps 30 --warmup 5
-run fx_add14 CANOPY_FX_ADD=14 -- --cut-off 0 --no-also --steps 30 --warmup 5
-run fx_add8u4 CANOPY_FX_ADD=8 CANOPY_FX_U=4 -- --cut-off 0 --no-also --steps 30 --warmup 5
-run fx_u4 CANOPY_FX_U=4 -- --cut-off 0 --no-also --steps 30 --warmup 5
-run fx_e10k X=1 -- --cut-off 0 --kernel 6 --no-also --steps 30 --warmup 5 --events 10000
-run head X=1 -- --no-also
-run head_e2e5 X=1 -- --no-also --events 200000 --steps 50
-run fx_e2e5 X=1 -- --no-also --events 200000 --steps 30 --cut-off 0
+run abl7 CANOPY_FR1_DEBUG=7 -- --no-also --steps 50
+run abl15 CANOPY_FR1_DEBUG=15 -- --no-also --steps 50
+run abl31 CANOPY_FR1_DEBUG=31 -- --no-also --steps 50
+run abl23 CANOPY_FR1_DEBUG=23 -- --no-also --steps 50
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(64) void k_ws_build(const int64_t* __restrict__ row
 
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* p, int64_t n, uint32_t v) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+    // no-op entries: col 0 -> the 64 sink slots, slot k of every group on its own (64 LDS adds on ONE address serialise)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v + (uint32_t)((i >> 2) & 63);
 }
 
 // ---- the stream kernel ---------------------------------------------------------------------------
