@@ -580,7 +580,6 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         ++ctx->timing_n;
     }
     int n_records = grid;
-    bool fused_pass = false; // the row kernel also ran the final reduce (k_fr1)
     if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
         if (want_mask) // slabs start at arbitrary rows: the kernel ORs partial words into a cleared mask
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
@@ -590,7 +589,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         // delta covers the rounding difference between the unordered pass-A sum and the CSR-order sum
         const double cand_cut = a.log_cut - (1e-9 + 1e-11 * (double)m->max_row_len);
         if (!ctx->d_fr_count) {
-            // {accumulator of the running pass, total of the last finished pass, ticket counter of the one-launch pass}
+            // {accumulator of the running pass, total of the last finished pass}
             HIP_TRY(ctx, hipMalloc(&ctx->d_fr_count, 4 * sizeof(unsigned long long)));
             HIP_TRY(ctx, hipHostMalloc(&ctx->h_fr_count, sizeof(unsigned long long)));
             // cleared once: a pass's final reduce leaves accumulator and tickets at zero for the next pass
@@ -630,18 +629,6 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
                                        m->n_fr_slabs, a.log_cut, params->limit_order, m->max_row_len, ctx->d_block_partials,
                                        ctx->d_fr_list, ctx->d_fr_cnt, ctx->d_fr_count, want_mask ? ctx->d_keep_mask : nullptr,
                                        grid_fx, ctx->stream));
-        } else if (fr1_enabled(m->n_events)) { // the whole pass in one launch: filter + exact pass + final reduce
-            canopy_model* mm = const_cast<canopy_model*>(m);
-            if (!mm->d_q8) HIP_TRY(ctx, hipMalloc(&mm->d_q8, (((size_t)m->n_events + 15) / 16) * 16 + 16));
-            const bool table_valid = !ctx->capturing && mm->q8_version == m->logp_version && mm->q8_version != 0 &&
-                                     mm->q8_log_cut == a.log_cut;
-            int g1 = 0;
-            HIP_TRY(ctx, launch_fr1(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, mm->d_q8, m->n_rows, m->n_events,
-                                    m->n_fr_slabs, a, want_mask ? ctx->d_keep_mask : nullptr, ctx->d_fr_count, ctx->d_partial,
-                                    ctx->d_gather, ctx->gather_world, ctx->gather_rank, ctx->n_cu, table_valid, &g1, ctx->stream));
-            mm->q8_version = m->logp_version;
-            mm->q8_log_cut = a.log_cut;
-            fused_pass = true;
         } else if (fr_filter_is_quantised(m->n_events)) {
             canopy_model* mm = const_cast<canopy_model*>(m);
             if (!mm->d_q8) HIP_TRY(ctx, hipMalloc(&mm->d_q8, (((size_t)m->n_events + 15) / 16) * 16 + 16));
@@ -659,7 +646,6 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
                                       ctx->stream));
         int unit_rows = slab_rows, units_per_slab = 1; // list units the exact pass walks
         if (variant == CANOPY_KERNEL_FIXED_SUM) fx_list_units(m->n_events, &unit_rows, &units_per_slab);
-        if (!fused_pass)
         HIP_TRY(ctx, launch_fr_refine(a, ctx->d_fr_list, ctx->d_fr_cnt, unit_rows, m->n_fr_slabs * units_per_slab,
                                       want_mask ? ctx->d_keep_mask : nullptr, grid, variant == CANOPY_KERNEL_FIXED_SUM, grid_fx,
                                       ctx->stream));
@@ -675,7 +661,6 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         HIP_TRY(ctx, launch_rows_kernel(variant, a, grid, ctx->stream));
     }
     if (!ctx->capturing) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
-    if (!fused_pass)
     HIP_TRY(ctx, launch_finalize(ctx->d_block_partials, n_records, ctx->d_partial, ctx->d_gather, ctx->gather_world,
                                  ctx->gather_rank,
                                  (variant == CANOPY_KERNEL_FILTER_REFINE || variant == CANOPY_KERNEL_FIXED_SUM) ? ctx->d_fr_count : nullptr,

@@ -237,11 +237,6 @@ hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64
                             int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint16_t* cand_list,
                             unsigned* cand_cnt, unsigned long long* cand_count, int n_cu, hipStream_t s);
 bool fr_filter_is_quantised(int32_t n_events);
-bool fr1_enabled(int32_t n_events);
-hipError_t launch_fr1(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp, uint8_t* q8_buf,
-                      int64_t n_rows, int32_t n_events, int64_t n_slabs, const RowKernelArgs& row, uint64_t* keep_mask,
-                      unsigned long long* cand_count, double* out, double* gather, int world, int rank, int n_cu,
-                      bool table_valid, int* grid_out, hipStream_t s);
 hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
                                uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs, double log_cut,
                                uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count, int n_cu,

@@ -324,15 +324,14 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int64_t G = (int64_t)gridDim.x;
-    const int NW = (abl & 32) ? 14 : kQ8Waves; // timing experiment (CANOPY_FR_DEBUG=32): only 14 of the 16 waves stream
     // the first chunks of a slab are requested BEFORE the workgroup-wide steps in front of it (table staging here,
     // the previous slab's end step in the loop): no slab starts with a cold stream
     uint4 q[U];
 #define FR_FIRST_CHUNKS(SLAB)                                                                       \
-    if ((SLAB) < n_slabs && wave < NW) {                                                            \
+    if ((SLAB) < n_slabs) {                                                                         \
         const int64_t f0 = fr_uload(fr_off + (SLAB)), f1 = fr_uload(fr_off + (SLAB) + 1);           \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                             \
-            const int64_t c = f0 + wave + (int64_t)u * NW;                                          \
+            const int64_t c = f0 + wave + (int64_t)u * kQ8Waves;                                    \
             q[u] = stream[(c < f1 ? c : total_chunks) * kWave + lane];                              \
         }                                                                                           \
     }
@@ -349,11 +348,11 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
     for (int64_t s = (int64_t)blockIdx.x; s < n_slabs; s += G) {
         const int64_t c0 = fr_uload(fr_off + s), c1 = fr_uload(fr_off + s + 1);
         if (abl & 16) { FR_FIRST_CHUNKS(s) } // A/B switch (CANOPY_FR_DEBUG=16): the slab's first chunks requested only now
-        for (int64_t cb = c0 + (wave < NW ? wave : (c1 - c0)); cb < c1; cb += (int64_t)U * NW) {
+        for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * kQ8Waves) {
             uint4 qn[U]; // next step's chunks first: nothing else is in the vector-memory queue
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t c = cb + (int64_t)(U + u) * NW;
+                const int64_t c = cb + (int64_t)(U + u) * kQ8Waves;
                 // timing ablation (CANOPY_FR_DEBUG=1, wrong results): every slab re-reads its first 64 chunks, which
                 // stay cache-resident -> the pass without its HBM stream
                 const int64_t cc = (abl & 1) ? c0 + ((c - c0) & 63) : c;
@@ -482,309 +481,6 @@ __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArg
             acc_merge(t, o);
         }
         acc_store(a.block_partials + (size_t)(part_offset + (int)blockIdx.x) * kAccDoubles, t);
-    }
-}
-
-// ---- the whole filter/refine pass in ONE launch ---------------------------------------------------------------
-// k_fr_filter_q8 + k_fr_refine + k_finalize are three dependent launches: at 1e8 rows their two boundaries and the
-// latency-bound tails cost ~5 % of the pass, at the 1.25e7-row shard of an 8-GPU run a third of it. k_fr1 is the
-// quantised filter with the other two folded in:
-//   * waves [0, 16 - RW) stream and filter slab k exactly as k_fr_filter_q8 does; meanwhile the last RW waves of the
-//     workgroup run the EXACT pass over the candidates of slab k-2, which sit in one of three list buffers in LDS:
-//     a lane recomputes one candidate row from the canonical CSR in CSR order (blocking loads -- these waves have
-//     nothing else to do, and a slab's ~100 candidates take less than the 6 us the slab streams for);
-//     a slab with more candidates than a list holds (4096 = half its rows) is listed in several turns;
-//   * the workgroup records are reduced by the LAST workgroup to finish (one agent-scope ticket counter,
-//     write-through record stores, sc1 loads: MI355X_MICROARCH.md, inter-workgroup visibility): the canopy_partial
-//     record, the all-reduce slot and the candidate count leave the same launch.
-// Everything reported still comes from the exact recomputation; the record does not depend on which workgroup is
-// last (fixed index order) nor on timing (list positions come from a prefix scan of ballots).
-constexpr int kFr1List = 4096; // candidates per list buffer
-constexpr int kFr1Bufs = 3;    // slab k's list is written while slab k-2's is read: k-1's may still be being written
-
-struct Fr1Args {
-    const uint4* stream; const int64_t* fr_off; int64_t total_chunks;
-    const uint8_t* q8; int32_t n_events; int64_t n_rows, n_slabs; int threshold;
-    RowKernelArgs row;           // canonical CSR, logp, log_cut, limit_order, row_offset, block_partials
-    uint64_t* keep_mask;         // nullable; pre-cleared, exact keep bits OR-ed in
-    unsigned long long* cand_count; // [0] accumulator, [1] total of the last finished pass, [2] ticket counter
-    double* out;                 // canopy_partial record
-    double* gather; int world, rank;
-    int abl; // timing ablations (CANOPY_FR1_DEBUG, wrong results): 1 no exact pass, 2 no candidate listing, 4 no filter LDS work
-};
-
-// The exact pass of k_fr1, software-pipelined: a lane carries one candidate per stage; each turn it finishes the row
-// whose logp values it requested last turn, requests the logp of the row whose columns arrived, the columns of the
-// row whose bounds arrived, and the bounds of a new candidate -- every load has a whole turn (one slab of streaming,
-// ~6 us) to come back, so nothing is waited for. Rows longer than 8 finish with blocking loads.
-struct Fr1Stage1 { int64_t r, b, e; bool on; };
-struct Fr1Stage2 { int64_t r, b; int len; int32_t c[8]; bool on; };
-struct Fr1Stage3 { int64_t r, b; int len; double v[8]; bool on; };
-
-__device__ __forceinline__ void fr1_step(Acc& acc, const RowKernelArgs& a, uint64_t* keep_mask, Fr1Stage1& p1, Fr1Stage2& p2,
-                                         Fr1Stage3& p3, const uint16_t* list, int n, int64_t base, int j) {
-    // stage 4: the gathered values are here -> the row's sum in CSR order, the exact filter, exp / log1p
-    if (__any(p3.on)) {
-        double sv = 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (u < p3.len) sv = sv + p3.v[u]; // plain adds, CSR order
-        if (p3.on && p3.len > 8) // long row: the rest with blocking loads
-            for (int64_t k = p3.b + 8; k < p3.b + p3.len; ++k) sv = sv + a.logp[a.col_idx[k]];
-        const bool keep = p3.on && (sv >= a.log_cut) && (a.limit_order == 0 || p3.len <= a.limit_order);
-        fold_kept_row(acc.rare, acc.l1p, acc.n_certain, sv, keep);
-        if (keep) {
-            acc.n_kept += 1.0;
-            // a lane meets its rows in ascending order (turn by turn, list position by position): ties keep the lower row
-            if (sv > acc.max_logp) { acc.max_logp = sv; acc.argmax = (double)(a.row_offset + p3.r); }
-            if (keep_mask != nullptr)
-                atomicOr(reinterpret_cast<unsigned long long*>(&keep_mask[p3.r >> 6]), 1ULL << (p3.r & 63));
-        }
-    }
-    // stage 3: the columns are here -> request their logp
-    p3.on = p2.on; p3.r = p2.r; p3.b = p2.b; p3.len = p2.len;
-    if (__any(p2.on)) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (p2.on && u < p2.len) p3.v[u] = a.logp[p2.c[u]];
-    }
-    // stage 2: the row bounds are here -> request the first 8 columns
-    p2.on = p1.on; p2.r = p1.r; p2.b = p1.b; p2.len = p1.on ? (int)(p1.e - p1.b) : 0;
-    if (__any(p1.on)) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (p1.on && u < p2.len) p2.c[u] = a.col_idx[p1.b + u];
-    }
-    // stage 1: this lane's candidate of the entering list -> request its row bounds
-    p1.on = j < n;
-    if (p1.on) {
-        p1.r = base + (int64_t)list[j];
-        p1.b = a.row_ptr[p1.r];
-        p1.e = a.row_ptr[p1.r + 1];
-    }
-}
-
-template <int U, int RW>
-__global__ __launch_bounds__(kQ8Threads) void k_fr1(Fr1Args A) {
-    constexpr int FWV = kQ8Waves - RW; // filtering waves
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned* sums = reinterpret_cast<unsigned*>(smem);
-    uint8_t* tab = reinterpret_cast<uint8_t*>(smem + kQ8SumsBytes);
-    const size_t tab_bytes = (((size_t)A.n_events + 15) / 16) * 16;
-    unsigned* s_cnt = reinterpret_cast<unsigned*>(smem + kQ8SumsBytes + tab_bytes);              // [128]
-    uint16_t* s_list = reinterpret_cast<uint16_t*>(smem + kQ8SumsBytes + tab_bytes + 512);       // [kFr1Bufs][kFr1List]
-    unsigned* s_flag = reinterpret_cast<unsigned*>(smem + kQ8SumsBytes + tab_bytes + 512 + (size_t)kFr1Bufs * kFr1List * 2); // [4]
-    const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    const int64_t G = (int64_t)gridDim.x;
-    for (int i = tid; i < kQ8SlabRows + 64; i += kQ8Threads) sums[i] = 0u;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(A.q8);
-        uint4* dst = reinterpret_cast<uint4*>(tab);
-        for (int i = tid; i < (A.n_events + 15) / 16; i += kQ8Threads) dst[i] = src[i];
-    }
-    Acc acc; // exact-pass waves only
-    acc_init(acc);
-    // Turns: one per slab of this workgroup (filtering waves: stream and filter the slab | exact-pass waves: one step
-    // of their pipeline, fed from the list written two turns ago; then everybody lists this slab's candidates), extra
-    // turns for a slab with more candidates than a list buffer holds (no filter work: its next 4096 candidates are
-    // listed), and five last turns that only drain the lists and the pipeline. The two kinds of wave run two separate
-    // loops over the same turn sequence (same barriers, same workgroup-uniform state): their register sets never meet.
-    const int64_t n_mine = A.n_slabs > (int64_t)blockIdx.x ? (A.n_slabs - 1 - (int64_t)blockIdx.x) / G + 1 : 0;
-    constexpr int NI = kQ8SlabRows / kQ8Threads;
-    unsigned long long n_cand = 0;
-    // the part of a turn every wave runs: the slab's candidate ballots and counts, the turn's list
-#define FR1_TURN_STATE                                                                                              \
-    unsigned long long m[NI];                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < NI; ++i) m[i] = 0ULL;                                                     \
-    int64_t k_slab = 0; int drain = 0, total = 0, trip = 0, turn = 0, n1 = 0, n2 = 0; int64_t base1 = 0, base2 = 0;
-#define FR1_TURN_HEAD                                                                                               \
-        const bool more_trips = trip * kFr1List < total;                                                            \
-        const bool filter = !more_trips && k_slab < n_mine;                                                         \
-        if (!more_trips && !filter && drain == 5) break;                                                            \
-        const int64_t s = (int64_t)blockIdx.x + k_slab * G;
-#define FR1_TURN_TAIL                                                                                               \
-        fr_barrier();                                                                                               \
-        n2 = n1; base2 = base1; n1 = 0;                                                                             \
-        if (filter && (A.abl & 16)) { ++k_slab; total = 0; }                                                        \
-        else if (filter) {                                                                                          \
-            const int64_t r0 = s * kQ8SlabRows;                                                                     \
-            _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                        \
-                const int rl = i * kQ8Threads + tid;                                                                \
-                const int sv = (int)sums[rl];                                                                       \
-                sums[rl] = 0u;                                                                                      \
-                m[i] = __ballot(r0 + rl < A.n_rows && sv <= A.threshold);                                           \
-            }                                                                                                       \
-            if (lane == 0) {                                                                                        \
-                _Pragma("unroll") for (int i = 0; i < NI; ++i) s_cnt[i * kQ8Waves + wave] = (unsigned)__builtin_popcountll(m[i]); \
-            }                                                                                                       \
-            if (tid < 64) sums[kQ8SlabRows + tid] = 0u; /* the sink */                                              \
-            fr_barrier();                                                                                           \
-            unsigned tot = s_cnt[lane * 2] + s_cnt[lane * 2 + 1]; /* every wave adds up the 128 counts */           \
-            _Pragma("unroll") for (int d = kWave / 2; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, kWave);            \
-            total = (int)__builtin_amdgcn_readfirstlane(tot);                                                       \
-            trip = 0;                                                                                               \
-            base1 = r0;                                                                                             \
-            n_cand += (unsigned long long)total; /* workgroup-uniform */                                            \
-            ++k_slab;                                                                                               \
-        } else if (!more_trips) {                                                                                   \
-            ++drain;                                                                                                \
-        }                                                                                                           \
-        if ((A.abl & 2) && filter) total = 0;                                                                       \
-        if (trip * kFr1List < total) { /* list the next (at most) 4096 candidates of the current slab */            \
-            const unsigned no_flags[NI] = {};                                                                       \
-            (void)fr_emit_candidates<NI, kQ8Waves>(m, no_flags, s_cnt, lane, wave, tid, s_list + (turn % kFr1Bufs) * kFr1List, \
-                                                   (unsigned)(trip * kFr1List), (unsigned)kFr1List);                \
-            const int left = total - trip * kFr1List;                                                               \
-            n1 = left < kFr1List ? left : kFr1List;                                                                 \
-            ++trip;                                                                                                 \
-        }
-    if (wave < FWV) {
-        // ================= filtering waves
-        uint4 q[U];
-#define FR1_FIRST_CHUNKS(SLAB)                                                                      \
-        if ((SLAB) < A.n_slabs) {                                                                   \
-            const int64_t f0 = fr_uload(A.fr_off + (SLAB)), f1 = fr_uload(A.fr_off + (SLAB) + 1);   \
-            _Pragma("unroll") for (int u = 0; u < U; ++u) {                                         \
-                const int64_t c = f0 + wave + (int64_t)u * FWV;                                     \
-                q[u] = A.stream[(c < f1 ? c : A.total_chunks) * kWave + lane]; /* past the end: the no-op chunk */ \
-            }                                                                                       \
-        }
-        FR1_FIRST_CHUNKS((int64_t)blockIdx.x)
-        fr_barrier();
-        FR1_TURN_STATE
-#pragma unroll 1
-        for (;; ++turn) {
-            FR1_TURN_HEAD
-            if (filter) {
-                const int64_t c0 = fr_uload(A.fr_off + s), c1 = fr_uload(A.fr_off + s + 1);
-                // the quantised filter: a ring of U chunks in flight per wave, chunk by chunk (stride = the number of
-                // filtering waves, so a slab's ~193 chunks leave at most FWV - 1 idle slots): chunk k is consumed, then its
-                // register is reloaded with chunk k + U. Loads are unconditional (a branch around a load makes the compiler
-                // drain the memory queue at the back edge): past the slab's end the no-op chunk is read and skipped.
-                for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * FWV) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int64_t cur = cb + (int64_t)u * FWV;
-                        if (cur < c1 && !(A.abl & 4)) {
-                            const uint32_t e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-                            unsigned v[4];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) v[k] = tab[e[k] >> kQ8RowBits];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                __hip_atomic_fetch_add(&sums[e[k] & kQ8RowMask], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                        const int64_t nx = cur + (int64_t)U * FWV;
-                        q[u] = A.stream[(nx < c1 ? nx : A.total_chunks) * kWave + lane];
-                    }
-                }
-                FR1_FIRST_CHUNKS(s + G) // the next slab's stream starts under this slab's end step
-            }
-            FR1_TURN_TAIL
-        }
-#undef FR1_FIRST_CHUNKS
-    } else {
-        // ================= exact-pass waves
-        fr_barrier();
-        Fr1Stage1 p1; Fr1Stage2 p2; Fr1Stage3 p3;
-        p1.on = false; p2.on = false; p3.on = false;
-        p1.r = 0; p1.b = 0; p1.e = 0; p2.r = 0; p2.b = 0; p2.len = 0; p3.r = 0; p3.b = 0; p3.len = 0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { p2.c[u] = 0; p3.v[u] = 0.0; }
-        FR1_TURN_STATE
-#pragma unroll 1
-        for (;; ++turn) {
-            FR1_TURN_HEAD
-            {
-                const uint16_t* list = s_list + ((turn + 1) % kFr1Bufs) * kFr1List; // written two turns ago
-                int j0 = (wave - FWV) * kWave;
-                if (!(A.abl & 8))
-                do { // one step per turn for the usual ~100 candidates; more only when a list holds more than RW * 64
-                    fr1_step(acc, A.row, A.keep_mask, p1, p2, p3, list, (A.abl & 1) ? 0 : n2, base2, j0 + lane);
-                    j0 += RW * kWave;
-                } while (j0 < n2);
-            }
-            FR1_TURN_TAIL
-        }
-    }
-#undef FR1_TURN_STATE
-#undef FR1_TURN_HEAD
-#undef FR1_TURN_TAIL
-    // -------- the workgroup's record
-    __syncthreads();
-    double* s_red = reinterpret_cast<double*>(smem); // the sums are dead
-    acc_wave_reduce(acc);
-    if (lane == 0) acc_store(s_red + wave * kAccDoubles, acc);
-    __syncthreads();
-    if (tid == 0) {
-        Acc t;
-        acc_load(t, s_red);
-        for (int w = 1; w < kQ8Waves; ++w) {
-            Acc o;
-            acc_load(o, s_red + w * kAccDoubles);
-            acc_merge(t, o);
-        }
-        acc_store(s_red + kQ8Waves * kAccDoubles, t);
-    }
-    __syncthreads();
-    // -------- publish it (write-through stores), count this workgroup in; the last one reduces all records
-    if (wave == 0) {
-        if (lane < kAccDoubles)
-            __hip_atomic_store(&A.row.block_partials[(size_t)blockIdx.x * kAccDoubles + lane], s_red[kQ8Waves * kAccDoubles + lane],
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0 && n_cand) atomicAdd(&A.cand_count[0], n_cand);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stores and the candidate add are performed before the ticket is taken
-        unsigned ticket = 0;
-        if (lane == 0) ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(&A.cand_count[2]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (lane == 0) s_flag[0] = (ticket == gridDim.x - 1) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (s_flag[0] == 0u) return;
-    // last workgroup: every record is in L2 (write-through) and is read around L1 (agent-scope loads)
-    {
-        Acc t;
-        acc_init(t);
-        for (int i = tid; i < (int)gridDim.x; i += kQ8Threads) {
-            double rec[kAccDoubles];
-#pragma unroll
-            for (int k = 0; k < kAccDoubles; ++k)
-                rec[k] = __hip_atomic_load(&A.row.block_partials[(size_t)i * kAccDoubles + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            Acc o;
-            acc_load(o, rec);
-            acc_merge(t, o);
-        }
-        acc_wave_reduce(t);
-        __syncthreads();
-        if (lane == 0) acc_store(s_red + wave * kAccDoubles, t);
-        __syncthreads();
-        if (tid == 0) {
-            Acc r;
-            acc_load(r, s_red);
-            for (int w = 1; w < kQ8Waves; ++w) {
-                Acc o;
-                acc_load(o, s_red + w * kAccDoubles);
-                acc_merge(r, o);
-            }
-            double* s_out = s_red + kQ8Waves * kAccDoubles;
-            const double rh = r.rare.s + r.rare.c, rl = (r.rare.s - rh) + r.rare.c;
-            const double lh = r.l1p.s + r.l1p.c, ll = (r.l1p.s - lh) + r.l1p.c;
-            s_out[0] = rh; s_out[1] = rl; s_out[2] = lh; s_out[3] = ll;
-            s_out[4] = r.n_kept; s_out[5] = r.n_certain; s_out[6] = r.max_logp; s_out[7] = r.argmax;
-            // hand the candidate total to the host side, reset the accumulator and the ticket counter for the next pass
-            const unsigned long long c = __hip_atomic_load(&A.cand_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            A.cand_count[1] = c;
-            __hip_atomic_store(&A.cand_count[0], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&A.cand_count[2], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        const double* s_out = s_red + kQ8Waves * kAccDoubles;
-        if (tid < kAccDoubles) A.out[tid] = s_out[tid];
-        if (A.gather != nullptr)
-            for (int i = tid; i < A.world * kAccDoubles; i += kQ8Threads)
-                A.gather[i] = (i / kAccDoubles == A.rank) ? s_out[i % kAccDoubles] : 0.0;
     }
 }
 
@@ -1388,58 +1084,6 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
     if (u == 1) Q8_GO(1); else if (u == 2) Q8_GO(2); else if (u == 3) Q8_GO(3); else if (u == 6) Q8_GO(6); else Q8_GO(4);
 #undef Q8_GO
     return hipGetLastError();
-}
-
-// The one-launch form of the quantised filter/refine pass (k_fr1): table build when needed, then filter + exact pass +
-// final reduce. cand_count: 3 u64 {accumulator, total of the last pass, ticket counter}, zero before the first launch.
-hipError_t launch_fr1(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp, uint8_t* q8_buf,
-                      int64_t n_rows, int32_t n_events, int64_t n_slabs, const RowKernelArgs& row, uint64_t* keep_mask,
-                      unsigned long long* cand_count, double* out, double* gather, int world, int rank, int n_cu,
-                      bool table_valid, int* grid_out, hipStream_t s) {
-    const double mag = -row.log_cut > 1.0 ? -row.log_cut : 1.0;
-    const double inv_step = (double)kQ8Levels / mag;
-    const double t = -row.log_cut * inv_step * (1.0 + 0x1.0p-28); // as launch_fr_filter_q8
-    const int threshold = t < 0.0 ? -1 : (t > 2.0e9 ? 2000000000 : (int)t);
-    hipError_t e = hipSuccess;
-    if (!table_valid) {
-        hipLaunchKernelGGL(k_fr_q8_table, dim3(grid_for(n_events, 256)), dim3(256), 0, s, logp, n_events, inv_step, q8_buf);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    static const int u = getenv("CANOPY_FR_QU") ? atoi(getenv("CANOPY_FR_QU")) : 4; // tuning only
-    static const int rw = getenv("CANOPY_FR_RW") ? atoi(getenv("CANOPY_FR_RW")) : 2; // tuning only (exact-pass waves)
-    const size_t lds = kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16 + 512 + (size_t)kFr1Bufs * kFr1List * 2 + 16;
-    int64_t grid = n_cu;
-    if (grid > n_slabs) grid = n_slabs;
-    if (grid < 1) grid = 1;
-    *grid_out = (int)grid;
-    Fr1Args A;
-    A.stream = reinterpret_cast<const uint4*>(stream); A.fr_off = fr_off; A.total_chunks = total_chunks;
-    A.q8 = q8_buf; A.n_events = n_events; A.n_rows = n_rows; A.n_slabs = n_slabs; A.threshold = threshold;
-    A.row = row; A.keep_mask = keep_mask; A.cand_count = cand_count; A.out = out; A.gather = gather; A.world = world; A.rank = rank;
-    static const int fr1_dbg = getenv("CANOPY_FR1_DEBUG") ? atoi(getenv("CANOPY_FR1_DEBUG")) : 0; // timing ablations only
-    A.abl = fr1_dbg;
-#define FR1_GO(UU, RR)                                                                                              \
-    do {                                                                                                            \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr1<UU, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        if (e != hipSuccess) return e;                                                                              \
-        hipLaunchKernelGGL((k_fr1<UU, RR>), dim3((unsigned)grid), dim3(kQ8Threads), lds, s, A);                     \
-        return hipGetLastError();                                                                                   \
-    } while (0)
-    if (rw == 1) { if (u == 8) FR1_GO(8, 1); if (u == 6) FR1_GO(6, 1); FR1_GO(4, 1); }
-    if (rw == 4) FR1_GO(4, 4);
-    if (u == 8) FR1_GO(8, 2);
-    if (u == 6) FR1_GO(6, 2);
-    if (u == 2) FR1_GO(2, 2);
-    FR1_GO(4, 2);
-#undef FR1_GO
-}
-
-bool fr1_enabled(int32_t n_events) {
-    static const bool split = getenv("CANOPY_FR_SPLIT") != nullptr; // A/B: the three-launch form
-    // the three LDS lists sit beside the table: up to 103 K events (beyond: the three-launch form)
-    return !split && fr_filter_is_quantised(n_events) &&
-           kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16 + 512 + (size_t)kFr1Bufs * kFr1List * 2 + 16 <= (size_t)160 * 1024;
 }
 
 hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, const unsigned* cand_cnt, int slab_rows,
