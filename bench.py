@@ -2,8 +2,11 @@
 """bench.py -- quantified cut-sets/sec of the hot path on N MI355X (BASELINE.json metric).
 
 A "step" is one quantification pass over the synthetic CSR resident in HBM: row kernels + final reduce and,
-at N > 1, the single RCCL all-reduce of the shard partials -- issued by libcanopy.so itself on the pass's stream
-(canopy_comm_*, no Python between kernel and collective).
+at N > 1, the single RCCL all-reduce of the shard partials -- issued by libcanopy.so itself right behind the final
+reduce (canopy_comm_*, no Python between kernel and collective). The K timed steps run un-instrumented, with the
+library's pass pipelining on (the latency-bound tail of step i -- exact pass, final reduce, all-reduce -- overlaps the
+HBM-bound row kernel of step i+1: canopy_ctx_set_pipeline; --no-pipeline for the serial form). Per-kernel durations
+(roofline, median / min per pass) come from a second, instrumented run of serial passes right after the timed region.
 
 Workload. N = 1: BASELINE config 3 -- 1e8 cut sets x 1e5 basic events, avg 6 nnz/row, fp64.
 N > 1 (default, `--scaling strong`): BASELINE config 4 -- the SAME 1e8-row model row-sharded N ways,
@@ -103,8 +106,9 @@ def main():
     ap.add_argument("--also-steps", type=int, default=30)
     ap.add_argument("--collective", choices=("lib", "torch"), default="lib",
                     help="lib: canopy_comm_* (ncclAllReduce issued by libcanopy.so); torch: torch.distributed all_reduce")
-    ap.add_argument("--serial-collective", action="store_true",
-                    help="A/B: the all-reduce on the pass's own stream instead of the communicator's (CANOPY_COMM_SERIAL=1)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="A/B: passes strictly one after the other on one stream (canopy_ctx_set_pipeline(0))")
+    ap.add_argument("--probe-steps", type=int, default=50, help="instrumented serial passes after the timed region")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="single-GPU rehearsal of a strong-scaling shard: run shard 0 of an N-way split of --rows")
     ap.add_argument("--rehearse-backend", default="",
@@ -114,8 +118,6 @@ def main():
                     help="rehearse the N>1 code path (communicator, gather slots, all-reduce) at world size 1")
     args = ap.parse_args()
 
-    if args.serial_collective:
-        os.environ["CANOPY_COMM_SERIAL"] = "1"
     import torch  # first: one HIP runtime shared in-process
     import torch.distributed as dist
     import canopy_amd
@@ -204,15 +206,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    ctx.set_pipeline(not args.no_pipeline)
     for _ in range(args.spinup):  # setup, like the model build: not a warm-up step, not timed
         step()
     ctx.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
-    ctx.timing_begin(args.steps)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps):  # the timed region: no per-pass events, nothing but the passes
         step()
     t_enqueued = time.perf_counter() - t0
     ctx.synchronize()
@@ -224,8 +226,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # instrumented probe: the same pass, serial, with HIP events around its kernels (per-kernel durations do not depend on
+    # the pipelining; timing them inside the timed region would put event records between the overlapped halves)
+    ctx.set_pipeline(False)
+    ctx.timing_begin(args.probe_steps)
+    for _ in range(args.probe_steps):
+        step()
+    fence()
     k_ms_sum, tot_ms_sum, n_timed = ctx.timing_end()
     launches = ctx.timing_launches(n_timed)
+    ctx.set_pipeline(not args.no_pipeline)
 
     collective_ms = None
     if comm is not None:
@@ -257,14 +267,19 @@ def main():
         for _ in range(5):
             ctx.quantify_async(model, prm0)
         ctx.synchronize()
-        ctx.timing_begin(args.also_steps)
         t0 = time.perf_counter()
         for _ in range(args.also_steps):
             ctx.quantify_async(model, prm0)
         ctx.synchronize()
         el0 = time.perf_counter() - t0
+        ctx.set_pipeline(False)  # instrumented serial probe, as for the headline
+        ctx.timing_begin(args.also_steps)
+        for _ in range(args.also_steps):
+            ctx.quantify_async(model, prm0)
+        ctx.synchronize()
         _, _, n0 = ctx.timing_end()
         l0 = ctx.timing_launches(n0)
+        ctx.set_pipeline(not args.no_pipeline)
         r0 = canopy_amd.combine_partials([ctx.fetch_partial()])
         v0 = ctx.last_kernel_variant()
         k_mean, k_med, k_min = stats([a for a, _ in l0])
@@ -331,10 +346,11 @@ def main():
                 "streamed_gbs": info.stream_bytes / (k_mean * 1e-3) / 1e9 if (info.stream_bytes and variant == 5) else None,
                 "avg_kernel_ms": k_mean, "median_kernel_ms": k_med, "min_kernel_ms": k_min,
                 "avg_pass_ms": p_mean, "median_pass_ms": p_med, "min_pass_ms": p_min, "launches_timed": n_timed,
+                "serial_pass_ms_note": "pass = row kernels + final reduce (+ all-reduce at N > 1), one pass at a time",
                 "host_enqueue_ms_per_step": t_enqueued * 1e3 / args.steps,
                 "last_collective_ms": collective_ms,
-                "collective_stream": None if comm is None else ("pass stream (serial)" if args.serial_collective else
-                                                                "own stream, overlapping the next pass"),
+                "pipelined": not args.no_pipeline,
+                "probe": "kernel / pass ms: %d instrumented serial passes after the timed region" % n_timed,
             },
             "result": {"rare_event": result.rare_event, "mcub": result.mcub, "n_kept": result.n_kept,
                        "argmax_row": result.argmax_row},

@@ -101,6 +101,7 @@ SIGNATURES = {
     "canopy_ctx_free": (None, [C.c_void_p]),
     "canopy_last_error": (C.c_char_p, [C.c_void_p]),
     "canopy_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "canopy_ctx_set_pipeline": (C.c_int, [C.c_void_p, C.c_int32]),
     "canopy_model_upload": (C.c_int, [C.c_void_p, C.POINTER(CsrView), C.c_uint32, C.POINTER(C.c_void_p)]),
     "canopy_model_synthetic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_void_p)]),

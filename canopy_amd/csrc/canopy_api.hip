@@ -44,14 +44,20 @@ struct CSumH {
     }
 };
 
-canopy_status ensure_block_partials(canopy_ctx* ctx, int grid) {
-    if (grid <= ctx->block_partials_cap) return CANOPY_OK;
-    if (ctx->d_block_partials) (void)hipFree(ctx->d_block_partials);
-    ctx->d_block_partials = nullptr;
-    ctx->block_partials_cap = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_block_partials, sizeof(double) * kAccDoubles * (size_t)grid));
-    ctx->block_partials_cap = grid;
+canopy_status ensure_block_partials(canopy_ctx* ctx, canopy_ctx::PassScratch& S, int grid) {
+    if (grid <= S.block_partials_cap) return CANOPY_OK;
+    if (S.d_block_partials) (void)hipFree(S.d_block_partials);
+    S.d_block_partials = nullptr;
+    S.block_partials_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&S.d_block_partials, sizeof(double) * kAccDoubles * (size_t)grid));
+    S.block_partials_cap = grid;
     ++ctx->scratch_gen; // captured passes hold the old pointer
+    return CANOPY_OK;
+}
+
+// Orders the context's stream behind the side stream's work (device-side wait, no host blocking).
+canopy_status join_side(canopy_ctx* ctx) {
+    HIP_TRY(ctx, canopy::ctx_join_side(ctx));
     return CANOPY_OK;
 }
 
@@ -77,6 +83,17 @@ void free_model_buffers(canopy_model* m) {
 }
 
 } // namespace
+
+hipError_t canopy::ctx_join_side(canopy_ctx* ctx) {
+    for (int k = 1; k < canopy_ctx::kLanes; ++k) { // lane 0 IS the context's stream
+        canopy_ctx::PassScratch& S = ctx->sets[k];
+        if (!S.pending) continue;
+        hipError_t e = hipStreamWaitEvent(ctx->stream, S.ev_done, 0);
+        if (e != hipSuccess) return e;
+        S.pending = false;
+    }
+    return hipSuccess;
+}
 
 extern "C" {
 
@@ -147,6 +164,18 @@ canopy_status canopy_ctx_create(const canopy_ctx_params* params, canopy_ctx** ou
         }
         for (auto& ev : ctx->ev_last)
             if (hipEventCreate(&ev) != hipSuccess) { st = CANOPY_ERR_HIP; break; }
+        if (st != CANOPY_OK) break;
+        ctx->sets[0].stream = ctx->stream;
+        ctx->sets[0].d_partial = ctx->d_partial;
+        for (int k = 0; k < canopy_ctx::kLanes && st == CANOPY_OK; ++k) {
+            canopy_ctx::PassScratch& S = ctx->sets[k];
+            if (k > 0 && (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess ||
+                          hipMalloc(&S.d_partial, sizeof(double) * CANOPY_PARTIAL_DOUBLES) != hipSuccess)) st = CANOPY_ERR_HIP;
+            if (st == CANOPY_OK && hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming) != hipSuccess) st = CANOPY_ERR_HIP;
+        }
+        if (st != CANOPY_OK) break;
+        static const bool no_pipe = getenv("CANOPY_NO_PIPELINE") != nullptr;
+        ctx->pipeline_on = !no_pipe;
     } while (0);
     if (st != CANOPY_OK) {
         (void)hipGetLastError();
@@ -160,19 +189,27 @@ canopy_status canopy_ctx_create(const canopy_ctx_params* params, canopy_ctx** ou
 void canopy_ctx_free(canopy_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (int k = 1; k < canopy_ctx::kLanes; ++k) if (ctx->sets[k].stream) (void)hipStreamSynchronize(ctx->sets[k].stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto ev : ctx->ev_last) if (ev) (void)hipEventDestroy(ev);
     for (auto ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
-    if (ctx->d_block_partials) (void)hipFree(ctx->d_block_partials);
+    for (auto& S : ctx->sets) {
+        if (S.d_block_partials) (void)hipFree(S.d_block_partials);
+        if (S.d_fr_list) (void)hipFree(S.d_fr_list);
+        if (S.d_fr_cnt) (void)hipFree(S.d_fr_cnt);
+        if (S.d_fr_count) (void)hipFree(S.d_fr_count);
+        if (S.ev_done) (void)hipEventDestroy(S.ev_done);
+    }
+    for (int k = 1; k < canopy_ctx::kLanes; ++k) {
+        if (ctx->sets[k].d_partial) (void)hipFree(ctx->sets[k].d_partial);
+        if (ctx->sets[k].stream) (void)hipStreamDestroy(ctx->sets[k].stream);
+    }
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
     if (ctx->d_row_logp) (void)hipFree(ctx->d_row_logp);
     if (ctx->d_keep_mask) (void)hipFree(ctx->d_keep_mask);
     if (ctx->d_importance) (void)hipFree(ctx->d_importance);
-    if (ctx->d_fr_count) (void)hipFree(ctx->d_fr_count);
     if (ctx->h_fr_count) (void)hipHostFree(ctx->h_fr_count);
-    if (ctx->d_fr_list) (void)hipFree(ctx->d_fr_list);
-    if (ctx->d_fr_cnt) (void)hipFree(ctx->d_fr_cnt);
     if (ctx->d_mc_hits) (void)hipFree(ctx->d_mc_hits);
     if (ctx->h_mc_hits) (void)hipHostFree(ctx->h_mc_hits);
     for (auto ev : ctx->ev_mc) if (ev) (void)hipEventDestroy(ev);
@@ -186,11 +223,20 @@ const char* canopy_last_error(const canopy_ctx* ctx) { return ctx ? ctx->last_er
 canopy_status canopy_ctx_synchronize(canopy_ctx* ctx) try {
     if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, canopy::ctx_join_side(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CANOPY_OK;
 } CANOPY_CATCH_ALL
 
-void* canopy_ctx_partials_device(canopy_ctx* ctx) { return ctx ? ctx->d_partial : nullptr; }
+canopy_status canopy_ctx_set_pipeline(canopy_ctx* ctx, int32_t enable) try {
+    if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, canopy::ctx_join_side(ctx));
+    ctx->pipeline_on = enable != 0;
+    return CANOPY_OK;
+} CANOPY_CATCH_ALL
+
+void* canopy_ctx_partials_device(canopy_ctx* ctx) { return ctx ? ctx->sets[ctx->last_set].d_partial : nullptr; }
 
 int32_t canopy_last_kernel_variant(const canopy_ctx* ctx) { return ctx ? ctx->last_variant : 0; }
 
@@ -200,6 +246,7 @@ canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* device_buffer,
         return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "gather buffer: need 0 <= rank < world_size");
     if (ctx->d_gather != static_cast<double*>(device_buffer)) ++ctx->scratch_gen;
     ctx->d_gather = static_cast<double*>(device_buffer);
+    for (auto& S : ctx->sets) S.d_gather = nullptr; // (canopy_comm_* gives every lane a buffer of its own afterwards)
     ctx->gather_world = device_buffer ? world_size : 0;
     ctx->gather_rank = device_buffer ? rank : 0;
     return CANOPY_OK;
@@ -354,6 +401,7 @@ canopy_status canopy_model_set_probabilities(canopy_ctx* ctx, canopy_model* m, c
     std::vector<double> logp((size_t)m->n_events);
     for (int32_t j = 0; j < m->n_events; ++j) logp[(size_t)j] = log(p[j]); // glibc log, once, on the host
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, canopy::ctx_join_side(ctx)); // a pipelined pass may still be reading the old values on the side stream
     if (m->n_events > 0)
         HIP_TRY(ctx, hipMemcpyAsync(m->d_logp, logp.data(), sizeof(double) * (size_t)m->n_events, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // logp is a stack-lifetime buffer
@@ -558,7 +606,26 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override
                                           : rows_kernel_default_grid(ctx->n_cu, variant, m->n_rows);
     const int grid_fx = variant == CANOPY_KERNEL_FIXED_SUM ? fx_sum_grid(ctx->n_cu, m->n_events, m->n_fr_slabs) : 0;
-    canopy_status st = ensure_block_partials(ctx, variant == CANOPY_KERNEL_WAVE_STREAM ? grid * 4 : grid + grid_fx);
+    // Pipelined pass: a sum-only FILTER_REFINE / FIXED_SUM pass takes the next lane (a stream with scratch, record and slot
+    // buffer of its own) and runs there from start to end; the device overlaps the lanes. Everything else runs on lane 0,
+    // the context's stream, ordered behind whatever the other lanes still hold.
+    const bool two_step = variant == CANOPY_KERNEL_FILTER_REFINE || variant == CANOPY_KERNEL_FIXED_SUM;
+    const bool pipelined = ctx->pipeline_on && two_step && !want_mask && !want_imp && !want_rows && !ctx->capturing &&
+                           !(ctx->comm && ctx->comm->deferred) && !(ctx->d_gather != nullptr && ctx->comm == nullptr);
+    canopy_status st = CANOPY_OK;
+    const int set = pipelined ? ctx->pipe_next : 0;
+    canopy_ctx::PassScratch& S = ctx->sets[set];
+    if (!pipelined) {
+        st = join_side(ctx);
+        if (st != CANOPY_OK) return st;
+    } else if (S.used) {
+        // the lane's previous pass must have finished: back-pressure on the HOST (it stays up to two passes ahead of the
+        // device), not a wait in a device queue
+        HIP_TRY(ctx, hipEventSynchronize(S.ev_done));
+    }
+    hipStream_t lane = S.stream; // every launch of this pass
+    double* const d_gather = S.d_gather ? S.d_gather : ctx->d_gather;
+    st = ensure_block_partials(ctx, S, variant == CANOPY_KERNEL_WAVE_STREAM ? grid * 4 : grid + grid_fx);
     if (st != CANOPY_OK) return st;
 
     RowKernelArgs a;
@@ -566,35 +633,36 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     a.n_rows = m->n_rows; a.row_offset = m->row_offset; a.n_events = m->n_events;
     a.log_cut = params->cut_off > 0.0 ? log(params->cut_off) : -INFINITY; // host glibc log, as the oracle
     a.limit_order = params->limit_order;
-    a.block_partials = ctx->d_block_partials;
+    a.block_partials = S.d_block_partials;
     a.row_logp_out = want_rows ? ctx->d_row_logp : nullptr;
     a.keep_mask_out = want_mask ? ctx->d_keep_mask : nullptr;
 
-    if (ctx->comm) { // this pass's slot buffer (two alternate, so the collective can trail the next pass's kernels)
-        canopy_status cst = comm_begin_pass(ctx);
-        if (cst != CANOPY_OK) return cst;
-    }
+    // HIP events around the pass only when somebody will read them (a timing region, or the synchronous canopy_quantify):
+    // every record is a marker packet between two kernels, ~5 us of queue time at the 1.25e7-row shard of an 8-GPU run
     hipEvent_t* ev = ctx->ev_last;
+    bool timed = ctx->want_last_timing && !ctx->capturing;
     if (ctx->timing_on && !ctx->capturing && ctx->timing_n < ctx->timing_max) {
         ev = &ctx->ev_pool[(size_t)ctx->timing_n * 3];
         ++ctx->timing_n;
+        timed = true;
     }
     int n_records = grid;
     if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
         if (want_mask) // slabs start at arbitrary rows: the kernel ORs partial words into a cleared mask
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
     }
-    if (!ctx->capturing) HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ev[0], lane));
     if (variant == CANOPY_KERNEL_FILTER_REFINE || variant == CANOPY_KERNEL_FIXED_SUM) {
         // delta covers the rounding difference between the unordered pass-A sum and the CSR-order sum
         const double cand_cut = a.log_cut - (1e-9 + 1e-11 * (double)m->max_row_len);
-        if (!ctx->d_fr_count) {
+        if (!S.d_fr_count) {
             // {accumulator of the running pass, total of the last finished pass}
-            HIP_TRY(ctx, hipMalloc(&ctx->d_fr_count, 4 * sizeof(unsigned long long)));
-            HIP_TRY(ctx, hipHostMalloc(&ctx->h_fr_count, sizeof(unsigned long long)));
-            // cleared once: a pass's final reduce leaves accumulator and tickets at zero for the next pass
-            HIP_TRY(ctx, hipMemsetAsync(ctx->d_fr_count, 0, 4 * sizeof(unsigned long long), ctx->stream));
+            HIP_TRY(ctx, hipMalloc(&S.d_fr_count, 4 * sizeof(unsigned long long)));
+            if (!ctx->h_fr_count) HIP_TRY(ctx, hipHostMalloc(&ctx->h_fr_count, sizeof(unsigned long long)));
+            // cleared once: a pass's final reduce leaves the accumulator at zero for the next pass on this set
+            HIP_TRY(ctx, hipMemsetAsync(S.d_fr_count, 0, 4 * sizeof(unsigned long long), lane));
         }
+        ctx->last_set = set;
         ctx->fr_pending_id = m->id;
         ctx->fr_pending_rows = m->n_rows;
         ctx->fr_pending_cut_off = params->cut_off;
@@ -602,18 +670,18 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         ctx->fr_pending_variant = variant;
         const int slab_rows = fr_slab_rows(m->n_events);
         const int64_t list_len = m->n_fr_slabs * slab_rows;
-        if (ctx->fr_list_cap < list_len || !ctx->d_fr_list) {
-            if (ctx->d_fr_list) (void)hipFree(ctx->d_fr_list);
-            ctx->d_fr_list = nullptr; ctx->fr_list_cap = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->d_fr_list, sizeof(uint16_t) * (size_t)(list_len > 0 ? list_len : 1)));
-            ctx->fr_list_cap = list_len; ++ctx->scratch_gen;
+        if (S.fr_list_cap < list_len || !S.d_fr_list) {
+            if (S.d_fr_list) (void)hipFree(S.d_fr_list);
+            S.d_fr_list = nullptr; S.fr_list_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&S.d_fr_list, sizeof(uint16_t) * (size_t)(list_len > 0 ? list_len : 1)));
+            S.fr_list_cap = list_len; ++ctx->scratch_gen;
         }
         const int64_t cnt_need = m->n_fr_slabs * 8; // the fixed-point pass keeps up to eight list units per slab
-        if (ctx->fr_cnt_cap < cnt_need || !ctx->d_fr_cnt) {
-            if (ctx->d_fr_cnt) (void)hipFree(ctx->d_fr_cnt);
-            ctx->d_fr_cnt = nullptr; ctx->fr_cnt_cap = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->d_fr_cnt, sizeof(unsigned) * (size_t)(cnt_need > 0 ? cnt_need : 1)));
-            ctx->fr_cnt_cap = cnt_need; ++ctx->scratch_gen;
+        if (S.fr_cnt_cap < cnt_need || !S.d_fr_cnt) {
+            if (S.d_fr_cnt) (void)hipFree(S.d_fr_cnt);
+            S.d_fr_cnt = nullptr; S.fr_cnt_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&S.d_fr_cnt, sizeof(unsigned) * (size_t)(cnt_need > 0 ? cnt_need : 1)));
+            S.fr_cnt_cap = cnt_need; ++ctx->scratch_gen;
         }
         if (want_mask && variant == CANOPY_KERNEL_FILTER_REFINE) // the refine pass ORs the exact keep bits into a cleared mask
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
@@ -621,34 +689,48 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             canopy_model* mm = const_cast<canopy_model*>(m);
             if (!mm->d_fx) HIP_TRY(ctx, hipMalloc(&mm->d_fx, sizeof(uint64_t) * (size_t)(m->n_events > 0 ? m->n_events : 1)));
             if (ctx->capturing || mm->fx_version != m->logp_version || mm->fx_version == 0) { // (a captured pass always rebuilds it)
+                if (!ctx->capturing) { // every lane reads the table: rebuilt behind all of them, and finished before any goes on
+                    st = join_side(ctx);
+                    if (st != CANOPY_OK) return st;
+                }
                 HIP_TRY(ctx, launch_fx_table(m->d_logp, m->n_events, mm->d_fx, ctx->stream));
+                if (!ctx->capturing) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                 mm->fx_version = m->logp_version;
             }
             // pass A writes records [0, grid_fx) and every word of the keep mask; the exact pass adds records [grid_fx, ..)
             HIP_TRY(ctx, launch_fx_sum(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, mm->d_fx, m->d_row_ptr, m->n_rows, m->n_events,
-                                       m->n_fr_slabs, a.log_cut, params->limit_order, m->max_row_len, ctx->d_block_partials,
-                                       ctx->d_fr_list, ctx->d_fr_cnt, ctx->d_fr_count, want_mask ? ctx->d_keep_mask : nullptr,
-                                       grid_fx, ctx->stream));
+                                       m->n_fr_slabs, a.log_cut, params->limit_order, m->max_row_len, S.d_block_partials,
+                                       S.d_fr_list, S.d_fr_cnt, S.d_fr_count, want_mask ? ctx->d_keep_mask : nullptr,
+                                       grid_fx, lane));
         } else if (fr_filter_is_quantised(m->n_events)) {
             canopy_model* mm = const_cast<canopy_model*>(m);
             if (!mm->d_q8) HIP_TRY(ctx, hipMalloc(&mm->d_q8, (((size_t)m->n_events + 15) / 16) * 16 + 16));
             // the 8-bit table depends on (logp, cut-off) only: rebuilt when either changed
             const bool table_valid = !ctx->capturing && mm->q8_version == m->logp_version && mm->q8_version != 0 &&
                                      mm->q8_log_cut == a.log_cut; // (a captured pass always rebuilds it: p may change between replays)
+            if (!table_valid && !ctx->capturing) { // every lane reads the table: rebuilt behind all of them (only when p or
+                st = join_side(ctx);               // the cut-off changed), on the pass's own lane, which the host then waits for
+                if (st != CANOPY_OK) return st;
+                if (lane != ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            }
             HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, mm->d_q8, m->n_rows,
-                                             m->n_events, m->n_fr_slabs, a.log_cut, ctx->d_fr_list, ctx->d_fr_cnt, ctx->d_fr_count,
-                                             ctx->n_cu, table_valid, ctx->stream));
+                                             m->n_events, m->n_fr_slabs, a.log_cut, S.d_fr_list, S.d_fr_cnt, S.d_fr_count,
+                                             ctx->n_cu, table_valid, lane));
+            if (!table_valid && !ctx->capturing) HIP_TRY(ctx, hipStreamSynchronize(lane));
             mm->q8_version = m->logp_version;
             mm->q8_log_cut = a.log_cut;
         } else
         HIP_TRY(ctx, launch_fr_filter(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, m->n_rows,
-                                      m->n_events, m->n_fr_slabs, cand_cut, ctx->d_fr_list, ctx->d_fr_cnt, ctx->d_fr_count, ctx->n_cu,
-                                      ctx->stream));
+                                      m->n_events, m->n_fr_slabs, cand_cut, S.d_fr_list, S.d_fr_cnt, S.d_fr_count, ctx->n_cu,
+                                      lane));
         int unit_rows = slab_rows, units_per_slab = 1; // list units the exact pass walks
         if (variant == CANOPY_KERNEL_FIXED_SUM) fx_list_units(m->n_events, &unit_rows, &units_per_slab);
-        HIP_TRY(ctx, launch_fr_refine(a, ctx->d_fr_list, ctx->d_fr_cnt, unit_rows, m->n_fr_slabs * units_per_slab,
+        const int64_t n_units = m->n_fr_slabs * units_per_slab;
+        const int64_t g_need = (2 * n_units + 3) / 4 > 0 ? (2 * n_units + 3) / 4 : 1; // two waves per unit, four per workgroup
+        if ((int64_t)grid > g_need) grid = (int)g_need; // a small shard does not pay for 2048 workgroups' records
+        HIP_TRY(ctx, launch_fr_refine(a, S.d_fr_list, S.d_fr_cnt, unit_rows, n_units,
                                       want_mask ? ctx->d_keep_mask : nullptr, grid, variant == CANOPY_KERNEL_FIXED_SUM, grid_fx,
-                                      ctx->stream));
+                                      lane));
         n_records = grid + grid_fx;
     } else if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
         HIP_TRY(ctx, launch_vs_kernel(a, m->d_vs_stream, m->d_vs_off, m->d_vs_slab_row, m->vs_total_chunks, m->n_slabs,
@@ -660,24 +742,29 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     } else {
         HIP_TRY(ctx, launch_rows_kernel(variant, a, grid, ctx->stream));
     }
-    if (!ctx->capturing) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
-    HIP_TRY(ctx, launch_finalize(ctx->d_block_partials, n_records, ctx->d_partial, ctx->d_gather, ctx->gather_world,
-                                 ctx->gather_rank,
-                                 (variant == CANOPY_KERNEL_FILTER_REFINE || variant == CANOPY_KERNEL_FIXED_SUM) ? ctx->d_fr_count : nullptr,
-                                 ctx->stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ev[1], lane));
+    HIP_TRY(ctx, launch_finalize(S.d_block_partials, n_records, S.d_partial, d_gather, ctx->gather_world,
+                                 ctx->gather_rank, two_step ? S.d_fr_count : nullptr, lane));
     ctx->last_variant = variant;
-    if (ctx->comm) { // K5: the one collective of the path, same stream, issued here (not by the host language)
-        canopy_status cst = comm_all_reduce_partials(ctx);
+    ctx->last_set = set;
+    if (ctx->comm) { // K5: the one collective of the path, issued here (not by the host language), behind the final reduce
+        canopy_status cst = comm_all_reduce_partials(ctx, lane, d_gather);
         if (cst != CANOPY_OK) return cst;
     }
-    if (!ctx->capturing) HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ev[2], lane));
+    if (pipelined) {
+        HIP_TRY(ctx, hipEventRecord(S.ev_done, lane));
+        S.used = true;
+        S.pending = set != 0;
+        ctx->pipe_next = (set + 1) % canopy_ctx::kLanes;
+    }
     if (want_imp) { // after the timed pass: one walk over the kept rows
         double* dst = ctx->ext_importance ? ctx->ext_importance : ctx->d_importance;
         HIP_TRY(ctx, hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(m->n_events > 0 ? m->n_events : 1), ctx->stream));
         HIP_TRY(ctx, launch_importance(ctx->d_keep_mask, m->n_rows, m->d_row_ptr, m->d_col_idx, m->d_logp, dst, ctx->stream));
     }
     ctx->last_has_importance = want_imp;
-    if (ev == ctx->ev_last) ctx->last_timed = !ctx->capturing;
+    if (ev == ctx->ev_last) ctx->last_timed = timed;
     ctx->last_has_row_logp = want_rows;
     ctx->last_has_mask = (params->flags & CANOPY_QUANT_KEEP_MASK) != 0;
     return CANOPY_OK;
@@ -686,11 +773,12 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
 canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* out) try {
     if (!ctx || !out) return CANOPY_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, ctx->d_partial, sizeof(double) * CANOPY_PARTIAL_DOUBLES,
+    HIP_TRY(ctx, canopy::ctx_join_side(ctx));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, ctx->sets[ctx->last_set].d_partial, sizeof(double) * CANOPY_PARTIAL_DOUBLES,
                                 hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->fr_pending_id)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fr_count, ctx->d_fr_count + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                                    ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fr_count, ctx->sets[ctx->last_set].d_fr_count + 1, sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out, ctx->h_partial, sizeof(canopy_partial));
     if (ctx->fr_pending_id) { // feedback for AUTO: a pass A that lists most rows is not worth its exact pass
@@ -756,9 +844,9 @@ canopy_status canopy_quantify(canopy_ctx* ctx, const canopy_model* m, const cano
                               canopy_quant_result* result) try {
     if (!result) return CANOPY_ERR_INVALID_ARGUMENT;
     const bool was_timing = ctx ? ctx->timing_on : false;
-    if (ctx) ctx->timing_on = false; // the synchronous call times itself with ev_last
+    if (ctx) { ctx->timing_on = false; ctx->want_last_timing = true; } // the synchronous call times itself with ev_last
     canopy_status st = canopy_quantify_async(ctx, m, params);
-    if (ctx) ctx->timing_on = was_timing;
+    if (ctx) { ctx->timing_on = was_timing; ctx->want_last_timing = false; }
     if (st != CANOPY_OK) return st;
     canopy_partial part;
     st = canopy_quantify_fetch(ctx, &part);
@@ -817,9 +905,11 @@ canopy_status canopy_graph_capture(canopy_ctx* ctx, const canopy_model* m, const
     if (!ctx || !m || !out) return CANOPY_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (ctx->comm) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "captured passes do not carry the cross-GPU collective: detach the communicator");
+    HIP_TRY(ctx, canopy::ctx_join_side(ctx));
     // one ordinary pass first: lazy layouts, scratch buffers and AUTO's choice are settled outside the capture
     canopy_status st = canopy_quantify_async(ctx, m, params);
     if (st != CANOPY_OK) return st;
+    HIP_TRY(ctx, canopy::ctx_join_side(ctx)); // (that pass may have been a pipelined one: nothing may be pending when the capture starts)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     canopy_graph* g = new (std::nothrow) canopy_graph();
     if (!g) return CANOPY_ERR_OUT_OF_MEMORY;
@@ -853,7 +943,9 @@ canopy_status canopy_graph_launch(canopy_ctx* ctx, canopy_graph* g) try {
                     "the context's scratch or output buffers were reallocated or re-pointed after this graph was captured "
                     "(a pass over a larger model, a first use of a per-row output, a new gather / importance buffer): capture again");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, canopy::ctx_join_side(ctx)); // the captured launches run on the context's stream (lane 0) and may rewrite tables
     HIP_TRY(ctx, hipGraphLaunch(g->exec, ctx->stream));
+    ctx->last_set = 0;
     // a captured FILTER_REFINE pass rewrites the model's quantised table with ITS cut-off: the eager cache key is void
     if (g->variant == CANOPY_KERNEL_FILTER_REFINE && g->model) g->model->q8_version = 0;
     ctx->last_variant = g->variant;
@@ -892,6 +984,7 @@ canopy_status canopy_timing_end(canopy_ctx* ctx, double* row_kernel_ms_sum, doub
     if (!ctx->timing_on) return fail(ctx, CANOPY_ERR_STATE, "timing region not open");
     ctx->timing_on = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, canopy::ctx_join_side(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     double ks = 0.0, ts = 0.0;
     for (int i = 0; i < ctx->timing_n; ++i) {

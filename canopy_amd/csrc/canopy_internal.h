@@ -26,8 +26,33 @@ struct canopy_ctx {
     int n_blocks_override = 0;
     size_t lds_per_block_max = 0;
 
-    double* d_block_partials = nullptr; // [block_partials_cap][8]
-    int block_partials_cap = 0;
+    // Lanes. A sum-only FILTER_REFINE / FIXED_SUM pass is a row kernel that streams the whole model (HBM-bound, every CU)
+    // followed by a latency-bound tail (exact pass over the listed rows, final reduce, with a communicator the
+    // all-reduce). Consecutive such passes rotate through THREE lanes, each a stream of its own with its own scratch,
+    // record and all-reduce slot buffer: a pass runs serially on its lane, and the device overlaps the lanes -- the next
+    // pass's row kernel takes the CUs the moment this pass's row kernel leaves them, while this pass's tail runs beside
+    // it. No event joins the lanes on the hot path (a cross-queue wait or record costs microseconds of queue time even
+    // when already satisfied): the host blocks before it reuses a lane until that lane's previous pass has finished.
+    // Lane 0 is the context's own stream; passes with per-row outputs and the other kernel variants run there, behind
+    // everything the other lanes still hold.
+    static constexpr int kLanes = 3;
+    struct PassScratch {
+        hipStream_t stream = nullptr;       // lane 0: the context's stream
+        double* d_block_partials = nullptr; // [block_partials_cap][8]
+        int block_partials_cap = 0;
+        uint16_t* d_fr_list = nullptr;      // [n_slabs * slab_rows] per-slab candidate lists (local row ids)
+        unsigned* d_fr_cnt = nullptr;       // their lengths
+        int64_t fr_list_cap = 0, fr_cnt_cap = 0;
+        unsigned long long* d_fr_count = nullptr; // [2]: candidate accumulator of the running pass, total of the finished one
+        double* d_partial = nullptr;        // the shard record this lane's final reduce writes (lane 0: ctx->d_partial)
+        double* d_gather = nullptr;         // this lane's all-reduce slot buffer when a communicator is attached
+        hipEvent_t ev_done = nullptr;       // end of the lane's last pass
+        bool pending = false;               // work on this lane the context's stream has not been ordered behind yet
+        bool used = false;
+    } sets[kLanes];
+    bool pipeline_on = true;      // canopy_ctx_set_pipeline / CANOPY_NO_PIPELINE
+    int pipe_next = 0;            // lane of the next pipelined pass
+    int last_set = 0;             // lane of the last pass (its record and candidate count are fetched from there)
     double* d_partial = nullptr;        // the shard record, 8 doubles
     double* h_partial = nullptr;        // pinned mirror
     double* d_gather = nullptr;         // caller-owned all-reduce buffer [world][8], optional
@@ -45,18 +70,15 @@ struct canopy_ctx {
 
     hipEvent_t ev_last[3] = {nullptr, nullptr, nullptr};
     bool last_timed = false;
+    bool want_last_timing = false; // set around the pass of the synchronous canopy_quantify
     // timing region
     std::vector<hipEvent_t> ev_pool; // 3 per launch
     int timing_max = 0, timing_n = 0;
     bool timing_on = false;
 
     // FILTER_REFINE: candidates flagged by the last filter pass (device counter, pinned mirror)
-    unsigned long long* d_fr_count = nullptr; // [2]: accumulator of the running filter pass, total of the last finished pass
     int32_t last_variant = 0;                 // CANOPY_KERNEL_* the last quantify pass ran
     unsigned long long* h_fr_count = nullptr;
-    uint16_t* d_fr_list = nullptr;  // [n_slabs * slab_rows] per-slab candidate lists (local row ids) of the last filter pass
-    unsigned* d_fr_cnt = nullptr;   // [n_slabs] their lengths
-    int64_t fr_list_cap = 0, fr_cnt_cap = 0;
     uint64_t fr_pending_id = 0;   // model id whose filter count is still on the device (0 = none)
     int64_t fr_pending_rows = 0;
     uint64_t fr_known_id = 0;     // last model id with a known candidate fraction
@@ -86,15 +108,11 @@ struct canopy_comm {
     canopy_ctx* ctx = nullptr;
     void* comm = nullptr;   // ncclComm_t
     int world = 1, rank = 0;
-    double* d_buf = nullptr; // [2][world][8] gather slots = the all-reduce buffers (two: consecutive passes alternate)
-    double* h_buf = nullptr; // pinned mirror of one of them
-    // The collective runs on its OWN stream behind an event of the pass's final reduce, so the next pass's kernels
-    // start while the (latency-bound, world * 64 B) all-reduce of this one is still on the wire.
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_fin[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    bool used[2] = {false, false};
-    int next = 0, last = -1; // buffer of the pass being enqueued / of the last enqueued pass
-    bool overlap = true;     // false (CANOPY_COMM_SERIAL=1): collective on the context's stream, one buffer
+    double* d_buf = nullptr; // [lanes][world][8] gather slots = the all-reduce buffers, one per lane of the context
+    double* h_buf = nullptr; // pinned mirror
+    hipEvent_t ev_fin = nullptr, ev_done = nullptr; // around the last all-reduce (timing)
+    bool issued = false;
+    double* last_buf = nullptr; // slot buffer of the last issued collective
     unsigned long long* d_mc = nullptr; // [2] {hits, trials} of the Monte-Carlo combine
     unsigned long long* h_mc = nullptr;
     bool mc_valid = false;
@@ -197,8 +215,10 @@ hipError_t synth_build_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int
 
 
 // comm_rccl.hip
-canopy_status comm_begin_pass(canopy_ctx* ctx);
-canopy_status comm_all_reduce_partials(canopy_ctx* ctx);
+// the single collective of a pass, enqueued on the stream its final reduce ran on
+canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t stream, double* buf);
+// orders the context's stream behind everything enqueued on the other lanes (device-side waits, no host blocking)
+hipError_t ctx_join_side(canopy_ctx* ctx);
 canopy_status comm_all_reduce_mc(canopy_ctx* ctx, const unsigned long long* d_hits, long long trials);
 
 // kernels_ws.hip

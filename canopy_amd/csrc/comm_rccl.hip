@@ -105,15 +105,10 @@ void comm_release(canopy_comm* c) { // device / host resources only (not the RCC
     if (c->h_buf) (void)hipHostFree(c->h_buf);
     if (c->d_mc) (void)hipFree(c->d_mc);
     if (c->h_mc) (void)hipHostFree(c->h_mc);
-    for (int b = 0; b < 2; ++b) {
-        if (c->ev_fin[b]) (void)hipEventDestroy(c->ev_fin[b]);
-        if (c->ev_done[b]) (void)hipEventDestroy(c->ev_done[b]);
-    }
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->ev_fin) (void)hipEventDestroy(c->ev_fin);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     delete c;
 }
-
-double* comm_buf(const canopy_comm* c, int b) { return c->d_buf + (size_t)b * CANOPY_PARTIAL_DOUBLES * (size_t)c->world; }
 
 canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, canopy_comm** out) {
     canopy_comm* c = new (std::nothrow) canopy_comm();
@@ -121,26 +116,22 @@ canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, ca
     c->ctx = ctx; c->comm = nc; c->world = world; c->rank = rank;
     HIPC_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bytes = sizeof(double) * CANOPY_PARTIAL_DOUBLES * (size_t)world;
-    static const bool serial = getenv("CANOPY_COMM_SERIAL") != nullptr; // A/B switch: collective on the pass's own stream
-    c->overlap = !serial;
-    hipError_t e = hipMalloc(&c->d_buf, 2 * bytes);
+    hipError_t e = hipMalloc(&c->d_buf, canopy_ctx::kLanes * bytes);
     if (e == hipSuccess) e = hipHostMalloc(&c->h_buf, bytes);
-    if (e == hipSuccess && c->overlap) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-        e = hipEventCreate(&c->ev_fin[b]);
-        if (e == hipSuccess) e = hipEventCreate(&c->ev_done[b]);
-    }
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_fin);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_done);
     if (e == hipSuccess) e = hipMalloc(&c->d_mc, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_mc, 2 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_buf, 0, 2 * bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_buf, 0, canopy_ctx::kLanes * bytes, ctx->stream);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         comm_release(c);
         return comm_fail(ctx, CANOPY_ERR_OUT_OF_MEMORY, std::string("comm buffers: ") + hipGetErrorString(e));
     }
-    // every later pass on this context fills slot `rank` and runs the collective
+    // every later pass on this context fills slot `rank` of its lane's buffer and runs the collective on it
     canopy_status st = canopy_ctx_set_gather_buffer(ctx, c->d_buf, world, rank);
     if (st != CANOPY_OK) { canopy_comm_free(c); return st; }
+    for (int k = 0; k < canopy_ctx::kLanes; ++k) ctx->sets[k].d_gather = c->d_buf + (size_t)k * CANOPY_PARTIAL_DOUBLES * (size_t)world;
     ctx->comm = c;
     *out = c;
     return CANOPY_OK;
@@ -150,40 +141,17 @@ canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, ca
 
 namespace canopy {
 
-// Called by canopy_quantify_async before it launches anything: picks the slot buffer of this pass. A buffer is reused
-// every second pass; its previous all-reduce must have finished before k_finalize overwrites it (an event wait on the
-// device, no host blocking -- by then it normally has).
-canopy_status comm_begin_pass(canopy_ctx* ctx) {
-    canopy_comm* c = ctx->comm;
-    if (!c) return CANOPY_OK;
-    const int b = (c->overlap && !c->deferred) ? c->next : 0;
-    if (c->overlap && !c->deferred && c->used[b]) HIPC_TRY(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done[b], 0));
-    ctx->d_gather = comm_buf(c, b); // (same world / rank as set at attach time)
-    return CANOPY_OK;
-}
-
-// Called by canopy_quantify_async right behind k_finalize: no host round trip. The collective goes to the
-// communicator's own stream behind an event, so the context's stream is free for the next pass at once.
-canopy_status comm_all_reduce_partials(canopy_ctx* ctx) {
+// Called by canopy_quantify_async right behind k_finalize, on the pass's lane: buf = that lane's slot buffer. (When the
+// stream changes from one call to the next RCCL itself orders the new collective behind the previous one.)
+canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t stream, double* buf) {
     canopy_comm* c = ctx->comm;
     if (!c || c->deferred) return CANOPY_OK;
-    const size_t count = (size_t)c->world * CANOPY_PARTIAL_DOUBLES;
-    if (!c->overlap) {
-        HIPC_TRY(ctx, hipEventRecord(c->ev_fin[0], ctx->stream));
-        RCCL_TRY(ctx, rccl()->AllReduce(c->d_buf, c->d_buf, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(c->comm), ctx->stream));
-        HIPC_TRY(ctx, hipEventRecord(c->ev_done[0], ctx->stream));
-        c->last = 0; c->used[0] = true;
-        return CANOPY_OK;
-    }
-    const int b = c->next;
-    double* buf = comm_buf(c, b);
-    HIPC_TRY(ctx, hipEventRecord(c->ev_fin[b], ctx->stream));
-    HIPC_TRY(ctx, hipStreamWaitEvent(c->stream, c->ev_fin[b], 0));
-    RCCL_TRY(ctx, rccl()->AllReduce(buf, buf, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(c->comm), c->stream));
-    HIPC_TRY(ctx, hipEventRecord(c->ev_done[b], c->stream));
-    c->used[b] = true;
-    c->last = b;
-    c->next = b ^ 1;
+    HIPC_TRY(ctx, hipEventRecord(c->ev_fin, stream));
+    RCCL_TRY(ctx, rccl()->AllReduce(buf, buf, (size_t)c->world * CANOPY_PARTIAL_DOUBLES, ncclDouble, ncclSum,
+                                    static_cast<ncclComm_t>(c->comm), stream));
+    HIPC_TRY(ctx, hipEventRecord(c->ev_done, stream));
+    c->issued = true;
+    c->last_buf = buf;
     return CANOPY_OK;
 }
 
@@ -191,6 +159,7 @@ canopy_status comm_all_reduce_partials(canopy_ctx* ctx) {
 canopy_status comm_all_reduce_mc(canopy_ctx* ctx, const unsigned long long* d_hits, long long trials) {
     canopy_comm* c = ctx->comm;
     if (!c || c->deferred) return CANOPY_OK; // one process, N devices: the host adds the N hit counts itself
+    HIPC_TRY(ctx, canopy::ctx_join_side(ctx)); // one communicator: its collectives stay in one stream order
     hipLaunchKernelGGL(k_mc_pack, dim3(1), dim3(1), 0, ctx->stream, c->d_mc, d_hits, (unsigned long long)trials);
     HIPC_TRY(ctx, hipGetLastError());
     RCCL_TRY(ctx, rccl()->AllReduce(c->d_mc, c->d_mc, 2, ncclUint64, ncclSum, static_cast<ncclComm_t>(c->comm), ctx->stream));
@@ -265,13 +234,14 @@ void canopy_comm_free(canopy_comm* c) {
     canopy_ctx* ctx = c->ctx;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
+        (void)canopy::ctx_join_side(ctx);
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         if (ctx->comm == c) {
             ctx->comm = nullptr;
             (void)canopy_ctx_set_gather_buffer(ctx, nullptr, 0, 0);
+            for (auto& S : ctx->sets) S.d_gather = nullptr;
         }
     }
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl()->handle) (void)rccl()->CommDestroy(static_cast<ncclComm_t>(c->comm));
     comm_release(c);
 }
@@ -306,7 +276,8 @@ canopy_status canopy_comm_quantify_all_async(canopy_comm* const* comms, const ca
     RCCL_TRY(c0, api->GroupStart());
     for (int i = 0; i < n; ++i) {
         canopy_comm* c = comms[i];
-        c->last = 0;
+        c->issued = true;
+        c->last_buf = c->d_buf;
         ncclResult_t r = api->AllReduce(c->d_buf, c->d_buf, (size_t)c->world * CANOPY_PARTIAL_DOUBLES, ncclDouble, ncclSum,
                                         static_cast<ncclComm_t>(c->comm), c->ctx->stream);
         if (r != ncclSuccess) {
@@ -322,11 +293,11 @@ canopy_status canopy_comm_fetch(canopy_comm* c, uint32_t flags, canopy_quant_res
     if (!c || !c->ctx || (!result && !parts)) return CANOPY_ERR_INVALID_ARGUMENT;
     canopy_ctx* ctx = c->ctx;
     HIPC_TRY(ctx, hipSetDevice(ctx->device));
-    if (c->last < 0) return comm_fail(ctx, CANOPY_ERR_STATE, "no pass has been enqueued since the communicator was attached");
+    if (!c->issued) return comm_fail(ctx, CANOPY_ERR_STATE, "no pass has been enqueued since the communicator was attached");
     const size_t bytes = sizeof(double) * CANOPY_PARTIAL_DOUBLES * (size_t)c->world;
-    hipStream_t cs = (c->overlap && !c->deferred) ? c->stream : ctx->stream; // the stream the collective ran on
-    HIPC_TRY(ctx, hipMemcpyAsync(c->h_buf, comm_buf(c, c->last), bytes, hipMemcpyDeviceToHost, cs));
-    HIPC_TRY(ctx, hipStreamSynchronize(cs));
+    HIPC_TRY(ctx, canopy::ctx_join_side(ctx)); // a pipelined pass ran its collective on the side stream
+    HIPC_TRY(ctx, hipMemcpyAsync(c->h_buf, c->last_buf ? c->last_buf : c->d_buf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC_TRY(ctx, hipStreamSynchronize(ctx->stream));
     static_assert(sizeof(canopy_partial) == sizeof(double) * CANOPY_PARTIAL_DOUBLES, "record layout");
     const canopy_partial* recs = reinterpret_cast<const canopy_partial*>(c->h_buf);
     if (parts) memcpy(parts, recs, bytes);
@@ -336,11 +307,11 @@ canopy_status canopy_comm_fetch(canopy_comm* c, uint32_t flags, canopy_quant_res
 
 canopy_status canopy_comm_last_collective_ms(canopy_comm* c, double* ms) try {
     if (!c || !c->ctx || !ms) return CANOPY_ERR_INVALID_ARGUMENT;
-    if (c->last < 0 || c->deferred) return comm_fail(c->ctx, CANOPY_ERR_STATE, "no collective to time");
+    if (!c->issued || c->deferred) return comm_fail(c->ctx, CANOPY_ERR_STATE, "no collective to time");
     HIPC_TRY(c->ctx, hipSetDevice(c->ctx->device));
-    HIPC_TRY(c->ctx, hipEventSynchronize(c->ev_done[c->last]));
+    HIPC_TRY(c->ctx, hipEventSynchronize(c->ev_done));
     float t = 0.f;
-    HIPC_TRY(c->ctx, hipEventElapsedTime(&t, c->ev_fin[c->last], c->ev_done[c->last]));
+    HIPC_TRY(c->ctx, hipEventElapsedTime(&t, c->ev_fin, c->ev_done));
     *ms = t;
     return CANOPY_OK;
 } CANOPY_CATCH_ALL

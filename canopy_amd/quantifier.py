@@ -63,6 +63,10 @@ class Context:
     def synchronize(self):
         capi.check(capi.lib().canopy_ctx_synchronize(self._h), "canopy_ctx_synchronize", self._h)
 
+    def set_pipeline(self, enable):
+        """Overlap the tail of a sum-only pass with the next pass's row kernel (canopy_ctx_set_pipeline; default on)."""
+        capi.check(capi.lib().canopy_ctx_set_pipeline(self._h, 1 if enable else 0), "canopy_ctx_set_pipeline", self._h)
+
     def partials_device_ptr(self):
         return capi.lib().canopy_ctx_partials_device(self._h)
 

@@ -86,8 +86,23 @@ CANOPY_API canopy_status canopy_ctx_create(const canopy_ctx_params* params, cano
 CANOPY_API void canopy_ctx_free(canopy_ctx* ctx);
 /* Last HIP / validation error text captured by this context ("" if none). Owned by the ctx. */
 CANOPY_API const char* canopy_last_error(const canopy_ctx* ctx);
-/* Block the host until everything enqueued on the context's stream has finished. */
+/* Block the host until everything the context has enqueued (on its stream and on its side stream) has finished. */
 CANOPY_API canopy_status canopy_ctx_synchronize(canopy_ctx* ctx);
+/*
+ * Pipelining of consecutive passes (default: on; CANOPY_NO_PIPELINE=1 in the environment turns it off for every
+ * context). A sum-only FILTER_REFINE / FIXED_SUM pass is a row kernel that streams the whole model (HBM-bound, every
+ * CU busy) followed by a latency-bound tail (exact pass over the listed rows, final reduce, and with a communicator
+ * the all-reduce). With pipelining on, consecutive such passes rotate through three internal lanes -- a stream, scratch,
+ * record and all-reduce slot buffer each -- and the device overlaps them: the next pass's row kernel takes the CUs as
+ * this pass's row kernel leaves them, while this pass's tail runs beside it. A sequence of passes (uncertainty trials,
+ * repeated quantification after canopy_model_set_probabilities, the benchmark's steps) is then paced by the row kernel
+ * alone. Nothing changes for the caller: results are those of the LAST enqueued pass and are fetched as before (every
+ * fetch / synchronize / set_probabilities call first orders the context's stream behind the other lanes); the host
+ * may block in canopy_quantify_async until the pass three back has finished; passes that ask for per-row outputs,
+ * keep masks or importance, all other kernel variants, and contexts with a caller-owned gather buffer
+ * (canopy_ctx_set_gather_buffer) run un-pipelined on the context's stream behind whatever is still in flight.
+ */
+CANOPY_API canopy_status canopy_ctx_set_pipeline(canopy_ctx* ctx, int32_t enable);
 
 /* ---- model: the CSR cut-set x basic-event incidence matrix, resident in HBM ----------------- */
 typedef struct canopy_model canopy_model;
@@ -248,7 +263,7 @@ CANOPY_API canopy_status canopy_quantify(canopy_ctx* ctx, const canopy_model* mo
                                          const canopy_quant_params* params,
                                          canopy_quant_result* result);
 
-/* Device address of the context's canopy_partial record (CANOPY_PARTIAL_DOUBLES doubles). */
+/* Device address of the canopy_partial record of the last enqueued pass (CANOPY_PARTIAL_DOUBLES doubles). */
 CANOPY_API void* canopy_ctx_partials_device(canopy_ctx* ctx);
 
 /*
@@ -280,11 +295,9 @@ CANOPY_API canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* dev
  * Monte-Carlo (K6): with a communicator attached (process-per-GPU shape) canopy_mc_run_async also sums
  * {hits, trials} over the ranks (one u64 all-reduce); canopy_comm_mc_fetch returns the global estimate.
  * canopy_comm_free detaches (the context returns to single-shard behaviour); free it before its context.
- * Streams: the all-reduce is enqueued on the communicator's OWN stream behind an event of the pass's final reduce,
- * into one of two alternating slot buffers, so the context's stream starts the next pass while the (latency-bound)
- * collective of this one is still in flight. canopy_comm_fetch waits for the collective of the LAST enqueued pass;
- * canopy_ctx_synchronize waits for the kernels only. CANOPY_COMM_SERIAL=1 in the environment puts the collective back
- * on the context's stream (A/B measurements).
+ * Streams: the all-reduce is enqueued right behind the pass's final reduce, on the stream that ran it -- for a pipelined
+ * pass (canopy_ctx_set_pipeline) its lane, so the next pass's row kernel streams while the (latency-bound) collective
+ * of this one is on the wire. canopy_comm_fetch waits for the LAST enqueued pass.
  */
 #define CANOPY_COMM_ID_BYTES 128
 typedef struct canopy_comm_id { char bytes[CANOPY_COMM_ID_BYTES]; } canopy_comm_id;
@@ -334,8 +347,9 @@ CANOPY_API canopy_status canopy_fetch_importance(canopy_ctx* ctx, const canopy_m
 CANOPY_API canopy_status canopy_ctx_set_importance_buffer(canopy_ctx* ctx, void* device_buffer, int32_t n_events);
 
 /*
- * Device time of the last `canopy_quantify_async` row kernel alone, measured with HIP events
- * on the context's stream (blocks until it has finished). Used by the benchmark's roofline.
+ * Device time of the row kernel(s) and of the whole pass of the last synchronous canopy_quantify (HIP events; blocks
+ * until they have completed). Asynchronous passes carry events only inside a timing region (canopy_timing_begin):
+ * every event record is a marker packet between two kernels, microseconds of queue time on a small shard.
  */
 CANOPY_API canopy_status canopy_last_kernel_ms(canopy_ctx* ctx, double* row_kernel_ms,
                                                double* total_ms);

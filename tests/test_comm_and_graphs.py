@@ -217,3 +217,46 @@ def test_config3_full_size_against_the_oracle(gpu_ctx, oracle, cut_off):
     assert rel(got.rare_event, want.rare_event) < TOL and rel(got.mcub, want.mcub) < TOL, variant
     if cut_off == 0.0:
         assert got.n_kept == n
+
+
+@pytest.mark.gpu
+def test_pipelined_passes_equal_serial_passes(canopy_lib, oracle):
+    """canopy_ctx_set_pipeline: consecutive sum-only passes rotate through three lanes and overlap on the device. What
+    comes back is the record of the LAST enqueued pass, bit for bit what the serial context gives -- also when the
+    probabilities change between passes, when a keep-mask pass (un-pipelined) is interleaved, and for the all-rows
+    fixed-point pass."""
+    import canopy_amd
+    from canopy_amd import _capi
+    n, e = 1_300_000, 30_000
+    row_ptr, col = oracle.synth_csr(SEED, n, e, 6, n_threads=_threads())
+    p = oracle.synth_probabilities(SEED, e)
+    scales = [1.0, 0.5, 2.0, 1.5, 0.25, 3.0, 1.0, 0.7]
+    out = {}
+    for pipe in (True, False):
+        with canopy_amd.Context(device=0) as ctx:
+            ctx.set_pipeline(pipe)
+            model = ctx.upload(row_ptr, col, e)
+            recs = []
+            for k, sc in enumerate(scales):
+                model.set_probabilities(np.minimum(1.0, p * sc))
+                for _ in range(1 + k % 3):  # several passes in flight per probability vector
+                    ctx.quantify_async(model, canopy_amd.default_params())
+                r = canopy_amd.combine_partials([ctx.fetch_partial()])
+                recs.append((r.rare_event, r.mcub, r.n_kept, r.argmax_row, r.max_logp))
+                if k == 3:  # an un-pipelined pass in between: exact keep mask of this vector
+                    ctx.quantify_async(model, canopy_amd.default_params(flags=_capi.QUANT_KEEP_MASK))
+                    mask = ctx.fetch_keep_mask(model)
+                    assert int(np.unpackbits(mask.view(np.uint8)).sum()) == r.n_kept
+                if k == 5:  # the all-rows pass rides the lanes too
+                    for _ in range(4):
+                        ctx.quantify_async(model, canopy_amd.default_params(cut_off=0.0))
+                    r0 = canopy_amd.combine_partials([ctx.fetch_partial()])
+                    assert r0.n_kept == n and ctx.last_kernel_variant() == _capi.KERNEL_FIXED_SUM
+                    recs.append((r0.rare_event, r0.mcub, r0.n_kept, r0.argmax_row, r0.max_logp))
+            out[pipe] = recs
+            model.close()
+    assert out[True] == out[False]
+    want = oracle.quantify(row_ptr, col, np.minimum(1.0, p * scales[-1]), n_threads=_threads(), want_rows=False)
+    last = out[True][-1]
+    assert last[2] == int(want.n_kept) and last[3] == int(want.argmax_row) and last[4] == want.max_logp
+    assert rel(last[0], want.rare_event) < TOL and rel(last[1], want.mcub) < TOL
