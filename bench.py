@@ -63,10 +63,25 @@ def cpu_baseline(ctx, canopy_amd, n_events, avg, p, sample_rows):
     }
 
 
+def traffic_for(variant, info, cut_off):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (benchmarks/pmc.sh + make_traffic.py): only
+    quoted when they were collected for the kernel variant and workload that just ran."""
+    for name in ("traffic.json", "traffic_fx.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            tj = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        if tj.get("variant") == variant and tj.get("rows") == info.n_rows and tj.get("n_events") == info.n_events \
+                and tj.get("cut_off") == cut_off:
+            return tj.get("hbm_bytes_per_launch")
+    return None
+
+
 KERNEL_LABELS = {1: "k_rows (lane per row, L2 gather)", 2: "k_rows (lane per row, LDS table)",
                  3: "k_ws (wave-slab stream, exact CSR-order sums)", 4: "k_vs (value scatter)",
                  5: "k_fr_filter_q8 + k_fr_refine (quantised conservative filter, then exact refine)",
-                 6: "k_fx_sum + k_fr_refine (order-independent fixed-point sums, exact refine of the undecided rows)"}
+                 6: "k_fx2 + k_fr_refine (order-independent fixed-point sums, exact refine of the undecided rows)"}
 
 
 def stats(xs):
@@ -290,6 +305,8 @@ def main():
             "kernel_ms": {"mean": k_mean, "median": k_med, "min": k_min},
             "pass_ms": {"mean": p_mean, "median": p_med, "min": p_min},
             "frac": info.algorithmic_bytes / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": traffic_for(v0, info, 0.0),
+            "frac_real": (traffic_for(v0, info, 0.0) / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_for(v0, info, 0.0) else None,
             "cut_sets_per_s": info.n_rows * args.also_steps / el0,
             "n_kept": r0.n_kept, "rare_event": r0.rare_event, "mcub": r0.mcub, "layout_build_s": t_prep0,
         }}
@@ -298,18 +315,7 @@ def main():
         k_mean, k_med, k_min = stats([a for a, _ in launches])
         p_mean, p_med, p_min = stats([b for _, b in launches])
         achieved = info.algorithmic_bytes / (k_mean * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes committed under profiles/ (benchmarks/pmc.sh): only quoted
-        # when they were collected for the kernel and workload that just ran
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("variant") == variant and tj.get("rows") == info.n_rows and tj.get("n_events") == info.n_events \
-                        and tj.get("cut_off") == args.cut_off:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = traffic_for(variant, info, args.cut_off)
         cand_frac = (cand[0] / cand[1]) if (cand and cand[1] and variant == 5) else None
         line = {
             "metric": "quantified cut-sets/sec", "value": total_rows * args.steps / elapsed, "unit": "cut-sets/s",

@@ -1,12 +1,22 @@
 #!/bin/bash
-# Collects the round's evidence on the GPU box: rocprofv3 kernel stats of the default bench command, then
-# the bench line itself. usage (via gpurun): bash benchmarks/evidence.sh <tag>  -> gpurun_out/<tag>_*
-set -eu
+# Collects a round's evidence on the GPU box: rocprofv3 kernel stats of the default bench command, the bench line
+# itself, the strong-scaling shard rehearsals (1/2, 1/4, 1/8 of the model on this one GPU, with and without pass
+# pipelining, with the library's RCCL all-reduce at world size 1). usage (via gpurun): bash benchmarks/evidence.sh <tag>
+set -u
 TAG=${1:-ev}
 R=$PWD
-mkdir -p "$R/gpurun_out"
+O=$R/gpurun_out
+mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${TAG}_stats" -o fr -- \
-  python3 "$R/bench.py" --no-cpu-baseline > "$R/gpurun_out/${TAG}_stats.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_stats" -o fr -- \
+  python3 "$R/bench.py" --no-cpu-baseline > "$O/${TAG}_stats.log" 2>&1 || echo "stats rc=$?"
 cd "$R"
-timeout -k 10 500 python bench.py > "gpurun_out/${TAG}_bench.json" 2> "gpurun_out/${TAG}_bench.err"
+timeout -k 10 500 python bench.py > "$O/${TAG}_bench.json" 2> "$O/${TAG}_bench.err" || echo "bench rc=$?"
+for n in 2 4 8; do
+  timeout -k 10 200 python bench.py --shard-of $n --no-also --no-cpu-baseline > "$O/${TAG}_shard$n.json" 2> "$O/${TAG}_shard$n.err" || echo "shard$n rc=$?"
+  timeout -k 10 200 python bench.py --shard-of $n --no-also --no-cpu-baseline --no-pipeline > "$O/${TAG}_shard${n}_serial.json" 2> "$O/${TAG}_shard${n}_serial.err" || echo "shard$n serial rc=$?"
+done
+timeout -k 10 200 python bench.py --shard-of 8 --force-dist --no-cpu-baseline > "$O/${TAG}_shard8_rccl.json" 2> "$O/${TAG}_shard8_rccl.err" || echo "rccl rc=$?"
+timeout -k 10 200 python bench.py --shard-of 8 --force-dist --no-cpu-baseline --no-pipeline > "$O/${TAG}_shard8_rccl_serial.json" 2> "$O/${TAG}_shard8_rccl_serial.err" || echo "rccl serial rc=$?"
+timeout -k 10 200 python bench.py --no-also --no-cpu-baseline --no-pipeline > "$O/${TAG}_serial.json" 2> "$O/${TAG}_serial.err" || echo "serial rc=$?"
+echo evidence done
