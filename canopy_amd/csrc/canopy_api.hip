@@ -611,6 +611,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     // the context's stream, ordered behind whatever the other lanes still hold.
     const bool two_step = variant == CANOPY_KERNEL_FILTER_REFINE || variant == CANOPY_KERNEL_FIXED_SUM;
     const bool pipelined = ctx->pipeline_on && two_step && !want_mask && !want_imp && !want_rows && !ctx->capturing &&
+                           !ctx->filter_only_request &&
                            !(ctx->comm && ctx->comm->deferred) && !(ctx->d_gather != nullptr && ctx->comm == nullptr);
     canopy_status st = CANOPY_OK;
     const int set = pipelined ? ctx->pipe_next : 0;
@@ -683,7 +684,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             HIP_TRY(ctx, hipMalloc(&S.d_fr_cnt, sizeof(unsigned) * (size_t)(cnt_need > 0 ? cnt_need : 1)));
             S.fr_cnt_cap = cnt_need; ++ctx->scratch_gen;
         }
-        if (want_mask && variant == CANOPY_KERNEL_FILTER_REFINE) // the refine pass ORs the exact keep bits into a cleared mask
+        if (want_mask && variant == CANOPY_KERNEL_FILTER_REFINE && !ctx->filter_only_request) // the refine pass ORs the exact keep bits into a cleared mask
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
         if (variant == CANOPY_KERNEL_FIXED_SUM) {
             canopy_model* mm = const_cast<canopy_model*>(m);
@@ -723,6 +724,16 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         HIP_TRY(ctx, launch_fr_filter(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, m->n_rows,
                                       m->n_events, m->n_fr_slabs, cand_cut, S.d_fr_list, S.d_fr_cnt, S.d_fr_count, ctx->n_cu,
                                       lane));
+        if (ctx->filter_only_request && variant == CANOPY_KERNEL_FILTER_REFINE) {
+            // the batch path lists, marks and compacts the candidates itself (kernels_batch.hip): nothing else to run
+            ctx->filter_only_done = true;
+            ctx->filter_only_slab_rows = slab_rows;
+            ctx->filter_only_slabs = m->n_fr_slabs;
+            ctx->last_variant = variant;
+            ctx->last_set = set;
+            ctx->fr_pending_id = 0; // its candidate count is consumed by the batch, not by AUTO's feedback
+            return CANOPY_OK;
+        }
         int unit_rows = slab_rows, units_per_slab = 1; // list units the exact pass walks
         if (variant == CANOPY_KERNEL_FIXED_SUM) fx_list_units(m->n_events, &unit_rows, &units_per_slab);
         const int64_t n_units = m->n_fr_slabs * units_per_slab;

@@ -71,6 +71,10 @@ struct canopy_ctx {
     hipEvent_t ev_last[3] = {nullptr, nullptr, nullptr};
     bool last_timed = false;
     bool want_last_timing = false; // set around the pass of the synchronous canopy_quantify
+    // batched quantification: "run only the filter of a FILTER_REFINE pass and leave its candidate lists in set 0"
+    bool filter_only_request = false, filter_only_done = false;
+    int filter_only_slab_rows = 0;
+    int64_t filter_only_slabs = 0;
     // timing region
     std::vector<hipEvent_t> ev_pool; // 3 per launch
     int timing_max = 0, timing_n = 0;

@@ -52,6 +52,11 @@ struct BatchState {
     int64_t c_cap = 0;
     int32_t* d_c_col = nullptr;    // [nnz_c]
     int64_t col_cap = 0;
+    int64_t* d_slab_kept = nullptr;// [n_slabs] kept candidates per slab -> exclusive prefix (fast path)
+    int64_t* d_slab_nnz = nullptr; // [n_slabs] their entries -> exclusive prefix
+    int64_t slab_cap = 0, slab_cap2 = 0;
+    int64_t* d_totals = nullptr;   // [2] n_c, nnz_c
+    int64_t* h_totals = nullptr;   // pinned
     double* d_parts = nullptr;     // [blocks][kpad][8]
     int64_t parts_cap = 0;
     double* d_out = nullptr;       // [kpad][8] canopy_partial records
@@ -68,9 +73,11 @@ struct BatchState {
 
 void batch_state_free(BatchState* b) {
     if (!b) return;
-    void* ptrs[] = {b->d_in, b->d_logpT, b->d_logp_max, b->d_word_off, b->d_c_row, b->d_c_row_ptr, b->d_c_col, b->d_parts, b->d_out};
+    void* ptrs[] = {b->d_in, b->d_logpT, b->d_logp_max, b->d_word_off, b->d_c_row, b->d_c_row_ptr, b->d_c_col, b->d_parts, b->d_out,
+                    b->d_slab_kept, b->d_slab_nnz, b->d_totals};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (b->h_out) (void)hipHostFree(b->h_out);
+    if (b->h_totals) (void)hipHostFree(b->h_totals);
     for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
 }
@@ -112,8 +119,11 @@ hipError_t grow(T** p, int64_t* cap, int64_t need) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
     *cap = 0;
-    hipError_t e = hipMalloc(p, sizeof(T) * (size_t)(need > 0 ? need : 1));
-    if (e == hipSuccess) *cap = need > 0 ? need : 1;
+    // a quarter of headroom: hipFree + hipMalloc are synchronous and cost hundreds of microseconds in the middle of a batch,
+    // and consecutive batches of one analysis differ by a few per cent in their candidate counts
+    const int64_t want = need > 0 ? need + need / 4 + 1 : 1;
+    hipError_t e = hipMalloc(p, sizeof(T) * (size_t)want);
+    if (e == hipSuccess) *cap = want;
     return e;
 }
 
@@ -185,6 +195,123 @@ __global__ __launch_bounds__(256) void k_batch_compact_cols(const int64_t* __res
     if (i >= n_c) return;
     const int64_t src = row_ptr[c_row[i]], dst = c_row_ptr[i], len = c_row_ptr[i + 1] - dst;
     for (int64_t k = 0; k < len; ++k) c_col[dst + k] = col_idx[src + k];
+}
+
+// ---- candidates straight from the filter's lists (the fast path at scale) --------------------------------
+// The envelope pass only needs the filter of FILTER_REFINE: its per-slab candidate lists already hold, in ascending
+// row order, a superset of the rows that survive under the envelope. Three small launches and ONE host read (the two
+// totals, to size the compact CSR) replace the keep mask, its 12.5 MB clear, the mask scans and the per-candidate
+// length scan: k_batch_mark recomputes each listed row exactly under the envelope (CSR order) and marks the survivors
+// in the list (bit 15) while counting them and their entries per slab; k_batch_scan_slabs turns the counts into
+// offsets; k_batch_emit writes the compact CSR. One wave per slab: the order stays ascending.
+__device__ __forceinline__ double batch_row_sum(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                                const double* __restrict__ logp, int64_t r, int* len_out) {
+    const int64_t b = row_ptr[r], e = row_ptr[r + 1];
+    double s = 0.0;
+    for (int64_t k0 = b; k0 < e; k0 += 8) {
+        int32_t c[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = (k0 + u < e) ? col_idx[k0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = logp[c[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k0 + u < e) s = s + v[u]; // plain adds, CSR order
+    }
+    *len_out = (int)(e - b);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_batch_mark(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                                    const double* __restrict__ logp_env, double log_cut, int32_t limit_order,
+                                                    uint16_t* __restrict__ cand_list, const unsigned* __restrict__ cand_cnt,
+                                                    int slab_rows, int64_t n_slabs, int64_t* __restrict__ slab_kept,
+                                                    int64_t* __restrict__ slab_nnz) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t GW = (int64_t)gridDim.x * 4;
+    for (int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < n_slabs; s += GW) {
+        const int n = (int)__builtin_amdgcn_readfirstlane(cand_cnt[s]);
+        const int64_t base = s * slab_rows;
+        long long kept = 0, nnz = 0; // wave-uniform
+        for (int j0 = 0; j0 < n; j0 += kWave) {
+            const bool on = j0 + lane < n;
+            const unsigned entry = on ? (unsigned)cand_list[base + j0 + lane] & 0x7FFFu : 0u;
+            int len = 0;
+            const double sv = on ? batch_row_sum(row_ptr, col_idx, logp_env, base + (int64_t)entry, &len) : 0.0;
+            const bool keep = on && (sv >= log_cut) && (limit_order == 0 || len <= limit_order);
+            if (on) cand_list[base + j0 + lane] = (uint16_t)(entry | (keep ? 0x8000u : 0u));
+            kept += __builtin_popcountll(__ballot(keep));
+            int l = keep ? len : 0;
+#pragma unroll
+            for (int d = kWave / 2; d >= 1; d >>= 1) l += __shfl_xor(l, d, kWave);
+            nnz += l;
+        }
+        if (lane == 0) { slab_kept[s] = kept; slab_nnz[s] = nnz; }
+    }
+}
+
+// exclusive prefix of the two per-slab count arrays, in place, by ONE workgroup; totals -> totals[0], totals[1]
+__global__ __launch_bounds__(1024) void k_batch_scan_slabs(int64_t* __restrict__ kept, int64_t* __restrict__ nnz, int64_t n,
+                                                           int64_t* __restrict__ totals) {
+    __shared__ long long s_a[1024], s_b[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024, lo = (int64_t)tid * per, hi = lo + per < n ? lo + per : n;
+    long long a = 0, b = 0;
+    for (int64_t i = lo; i < hi; ++i) { a += kept[i]; b += nnz[i]; }
+    s_a[tid] = a; s_b[tid] = b;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan of the 1024 thread sums
+        const long long xa = tid >= d ? s_a[tid - d] : 0, xb = tid >= d ? s_b[tid - d] : 0;
+        __syncthreads();
+        s_a[tid] += xa; s_b[tid] += xb;
+        __syncthreads();
+    }
+    long long ra = s_a[tid] - a, rb = s_b[tid] - b; // exclusive prefix of this thread's range
+    for (int64_t i = lo; i < hi; ++i) {
+        const long long ka = kept[i], kb = nnz[i];
+        kept[i] = ra; nnz[i] = rb;
+        ra += ka; rb += kb;
+    }
+    if (tid == 1023) { totals[0] = s_a[1023]; totals[1] = s_b[1023]; }
+}
+
+__global__ __launch_bounds__(256) void k_batch_emit(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                                    const uint16_t* __restrict__ cand_list, const unsigned* __restrict__ cand_cnt,
+                                                    int slab_rows, int64_t n_slabs, const int64_t* __restrict__ slab_row_off,
+                                                    const int64_t* __restrict__ slab_nnz_off, int64_t* __restrict__ c_row,
+                                                    int64_t* __restrict__ c_row_ptr, int32_t* __restrict__ c_col) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t GW = (int64_t)gridDim.x * 4;
+    if (blockIdx.x == 0 && threadIdx.x == 0) c_row_ptr[0] = 0;
+    for (int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < n_slabs; s += GW) {
+        const int n = (int)__builtin_amdgcn_readfirstlane(cand_cnt[s]);
+        const int64_t base = s * slab_rows;
+        int64_t pos = slab_row_off[s], off = slab_nnz_off[s]; // wave-uniform running positions
+        for (int j0 = 0; j0 < n; j0 += kWave) {
+            const bool on = j0 + lane < n;
+            const unsigned entry = on ? (unsigned)cand_list[base + j0 + lane] : 0u;
+            const bool keep = on && (entry & 0x8000u) != 0;
+            const int64_t r = base + (int64_t)(entry & 0x7FFFu);
+            const int64_t b = keep ? row_ptr[r] : 0;
+            const int len = keep ? (int)(row_ptr[r + 1] - b) : 0;
+            const unsigned long long m = __ballot(keep);
+            int incl = len; // inclusive prefix of the kept lengths in lane order
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const int o = __shfl_up(incl, d, kWave);
+                if (lane >= d) incl += o;
+            }
+            if (keep) {
+                const int64_t i = pos + (int64_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const int64_t dst = off + incl - len;
+                c_row[i] = r;
+                c_row_ptr[i + 1] = off + incl;
+                for (int k = 0; k < len; ++k) c_col[dst + k] = col_idx[b + k];
+            }
+            pos += __builtin_popcountll(m);
+            off += __shfl(incl, kWave - 1, kWave);
+        }
+    }
 }
 
 // ---- the K-trial row kernel ---------------------------------------------------------------------------
@@ -377,19 +504,60 @@ canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* m, cons
     m->has_p = true;
     ++m->logp_version; // the filter's quantised table must be rebuilt for the envelope ...
     ctx->timing_on = false;
+    ctx->filter_only_request = true; // at scale AUTO runs FILTER_REFINE: only its filter is needed (lists instead of a mask)
+    ctx->filter_only_done = false;
     canopy_status st = canopy_quantify_async(ctx, m, &cprm);
+    ctx->filter_only_request = false;
+    const bool fast = st == CANOPY_OK && ctx->filter_only_done;
     canopy_partial env;
-    if (st == CANOPY_OK) st = canopy_quantify_fetch(ctx, &env);
+    memset(&env, 0, sizeof(env));
+    if (st == CANOPY_OK && !fast) st = canopy_quantify_fetch(ctx, &env);
+    int64_t n_c = (int64_t)env.n_kept, nnz_c = 0;
+    if (fast) {
+        // ---- 3a. mark the exact survivors in the lists, count per slab, scan, ONE host read of the two totals
+        canopy_ctx::PassScratch& S = ctx->sets[0];
+        const int64_t n_slabs = ctx->filter_only_slabs;
+        const int slab_rows = ctx->filter_only_slab_rows;
+        hipError_t e = grow(&b->d_slab_kept, &b->slab_cap, n_slabs);
+        if (e == hipSuccess) e = grow(&b->d_slab_nnz, &b->slab_cap2, n_slabs);
+        if (e == hipSuccess && !b->d_totals) e = hipMalloc(&b->d_totals, 2 * sizeof(int64_t));
+        if (e == hipSuccess && !b->h_totals) e = hipHostMalloc(&b->h_totals, 2 * sizeof(int64_t));
+        const double log_cut = prm.cut_off > 0.0 ? log(prm.cut_off) : -INFINITY;
+        const int g = grid_for(n_slabs, 4, 4096);
+        if (e == hipSuccess) e = hipMemsetAsync(S.d_fr_count, 0, 2 * sizeof(unsigned long long), ctx->stream); // (the filter's total: no final reduce took it)
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_batch_mark, dim3(g), dim3(256), 0, ctx->stream, (const int64_t*)m->d_row_ptr, (const int32_t*)m->d_col_idx,
+                               (const double*)b->d_logp_max, log_cut, prm.limit_order, S.d_fr_list, (const unsigned*)S.d_fr_cnt, slab_rows,
+                               n_slabs, b->d_slab_kept, b->d_slab_nnz);
+            hipLaunchKernelGGL(k_batch_scan_slabs, dim3(1), dim3(1024), 0, ctx->stream, b->d_slab_kept, b->d_slab_nnz, n_slabs, b->d_totals);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(b->h_totals, b->d_totals, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) { n_c = b->h_totals[0]; nnz_c = b->h_totals[1]; }
+        if (e == hipSuccess) e = grow(&b->d_c_row_ptr, &b->c_cap, n_c + 1);
+        if (e == hipSuccess) e = grow(&b->d_c_row, &b->c_row_cap, n_c);
+        if (e == hipSuccess) e = grow(&b->d_c_col, &b->col_cap, nnz_c);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_batch_emit, dim3(g), dim3(256), 0, ctx->stream, (const int64_t*)m->d_row_ptr, (const int32_t*)m->d_col_idx,
+                               (const uint16_t*)S.d_fr_list, (const unsigned*)S.d_fr_cnt, slab_rows, n_slabs, (const int64_t*)b->d_slab_kept,
+                               (const int64_t*)b->d_slab_nnz, b->d_c_row, b->d_c_row_ptr, b->d_c_col);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            st = fail(ctx, e == hipErrorOutOfMemory ? CANOPY_ERR_OUT_OF_MEMORY : CANOPY_ERR_HIP, std::string("batch candidates: ") + hipGetErrorString(e));
+        }
+    }
     m->d_logp = saved_logp;
     m->has_p = saved_has_p;
     ++m->logp_version; // ... and again for the model's own probabilities
     ctx->timing_on = was_timing;
     if (st != CANOPY_OK) return st;
-    const int64_t n_c = (int64_t)env.n_kept;
     const int64_t n_words = (m->n_rows + 63) / 64;
 
-    // ---- 3. compact the candidates
-    int64_t nnz_c = 0;
+    // ---- 3b. (other kernel variants) compact the candidates out of the keep mask
+    if (!fast) {
     HIP_TRY(ctx, grow(&b->d_c_row_ptr, &b->c_cap, n_c + 1));
     HIP_TRY(ctx, grow(&b->d_c_row, &b->c_row_cap, n_c));
     if (n_c > 0) {
@@ -413,6 +581,7 @@ canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* m, cons
     } else {
         HIP_TRY(ctx, grow(&b->d_c_col, &b->col_cap, 1));
     }
+    } // !fast
     HIP_TRY(ctx, hipEventRecord(b->ev[1], ctx->stream));
 
     // ---- 4. K trials over the compact CSR, 5. one record per trial
