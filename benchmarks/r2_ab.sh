@@ -11,16 +11,10 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run head X=1 -- --no-also --steps 100
-run head_nopipe X=1 -- --no-also --steps 100 --no-pipeline
-run shard8 X=1 -- --shard-of 8 --no-also
-run shard8_nopipe X=1 -- --shard-of 8 --no-also --no-pipeline
-run shard8_dist X=1 -- --shard-of 8 --force-dist
-run shard8_dist_nopipe X=1 -- --shard-of 8 --force-dist --no-pipeline
-run shard4 X=1 -- --shard-of 4 --no-also
-run shard2 X=1 -- --shard-of 2 --no-also
-run fx_default X=1 -- --cut-off 0 --no-also --steps 30 --warmup 5
-run full X=1 -- --steps 100
+run e2e5 X=1 -- --no-also --events 200000 --steps 100
+run e2e5_u2 CANOPY_FR_QU=2 -- --no-also --events 200000 --steps 100
+run e2e5_u3 CANOPY_FR_QU=3 -- --no-also --events 200000 --steps 100
+run e2e5_u6 CANOPY_FR_QU=6 -- --no-also --events 200000 --steps 100
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):

@@ -374,7 +374,7 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
     info->device_bytes = m->device_bytes;
     info->stream_bytes = 0;
     if (m->fr_state == 1)
-        info->stream_bytes = m->fr_total_chunks * 1024 + (m->n_fr_slabs + 1) * 8 + m->n_fr_slabs * 8 +
+        info->stream_bytes = m->fr_total_chunks * 1024 + (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8 + m->n_fr_slabs * 8 +
                              (int64_t)m->n_events * 8;
     else if (m->vs_state == 1)
         info->stream_bytes = m->vs_total_chunks * 1024 + (m->n_slabs + 1) * 16 + (m->n_rows + 1) * 8 + (int64_t)m->n_events * 8;
@@ -426,11 +426,11 @@ int auto_variant(const canopy_model* m) {
 canopy_status build_fr(canopy_ctx* ctx, canopy_model* m) {
     if (m->fr_state != 0) return CANOPY_OK;
     bool ok = false;
-    HIP_TRY(ctx, fr_offsets(m->d_row_ptr, m->n_rows, m->n_events, &m->d_fr_off, &m->fr_total_chunks, &m->n_fr_slabs, &ok, ctx->stream));
+    HIP_TRY(ctx, fr_offsets(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, &m->d_fr_off, &m->fr_total_chunks, &m->n_fr_slabs, &ok, ctx->stream));
     if (!ok) { m->fr_state = -1; return CANOPY_OK; }
     HIP_TRY(ctx, fr_build_sorted32(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, m->d_fr_off, m->fr_total_chunks,
                                    m->n_fr_slabs, &m->d_fr_stream, ctx->stream));
-    m->device_bytes += (m->fr_total_chunks + 1) * 1024 + (m->n_fr_slabs + 1) * 8;
+    m->device_bytes += (m->fr_total_chunks + 1) * 1024 + (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8;
     m->fr_state = 1;
     return CANOPY_OK;
 }

@@ -251,7 +251,8 @@ hipError_t launch_vs_kernel(const RowKernelArgs& ra, const uint32_t* stream, con
 // kernels_fr.hip
 int fr_max_events();
 int fr_refine_grid(int n_cu);
-hipError_t fr_offsets(const int64_t* d_row_ptr, int64_t n_rows, int32_t n_events, int64_t** d_fr_off_out,
+int fr_parts(int32_t n_events); // column parts of the slab stream (1 up to 112 K events): offsets are per (slab, part)
+hipError_t fr_offsets(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events, int64_t** d_fr_off_out,
                       int64_t* total_chunks_out, int64_t* n_slabs_out, bool* ok, hipStream_t s);
 hipError_t fr_build_sorted32(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events,
                              const int64_t* d_fr_off, int64_t total_chunks, int64_t n_slabs, uint32_t** d_stream_out,

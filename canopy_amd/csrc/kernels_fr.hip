@@ -56,9 +56,32 @@ struct FrCfg {
 constexpr int kQ8MaxEvents = 112 * 1024; // 8-bit table + 8192 u32 row sums + 128 counts must fit the 160 KiB of LDS
 constexpr int kQ8Levels = 224;           // threshold level; entries clamp at 255 (alone enough to kill a row)
 
-bool fr_use_q8(int32_t n_events) {
+// Beyond 112 K events the 8-bit table no longer fits LDS beside the row sums: the columns are cut into H = 2 or 3 PARTS
+// (whole column buckets, <= 112 K events each). The stream of a slab keeps its parts apart (each padded to whole chunks,
+// one chunk offset per (slab, part)), and the quantised filter makes H sweeps over its slabs with one part of the table
+// resident per sweep, carrying every row's partial sum from sweep to sweep as a saturated u16 in the (not yet written)
+// candidate-list buffer: +4 B per row and part boundary on a 24 B-per-cut-set stream instead of a gathered fp64 filter.
+constexpr int kQ8MaxParts = 3;
+constexpr int kFrBucketsC = 512; // column buckets of the builder's counting sort (= kFrBuckets below)
+
+bool fr_q8_allowed() {
     static const bool off = getenv("CANOPY_FR_NOQ8") != nullptr; // tuning only
-    return !off && n_events <= kQ8MaxEvents;
+    return !off;
+}
+bool fr_use_q8(int32_t n_events) { return fr_q8_allowed() && n_events <= kQ8MaxParts * kQ8MaxEvents && n_events <= (1 << 18); }
+int fr_parts_for(int32_t n_events) {
+    if (!fr_use_q8(n_events) || n_events <= kQ8MaxEvents) return 1;
+    return (n_events + kQ8MaxEvents - 1) / kQ8MaxEvents;
+}
+__host__ __device__ inline unsigned fr_bucket_of(uint32_t c, uint64_t ne) { return (unsigned)(((uint64_t)c * (uint64_t)kFrBucketsC) / ne); }
+__host__ __device__ inline int fr_part_of_bucket(unsigned b, int H) { return (int)((b * (unsigned)H) / (unsigned)kFrBucketsC); }
+// first column of part h (h = H: n_events)
+int32_t fr_part_first_col(int h, int H, int32_t n_events) {
+    if (h <= 0) return 0;
+    if (h >= H) return n_events;
+    unsigned b = 0;
+    while (b < (unsigned)kFrBucketsC && fr_part_of_bucket(b, H) < h) ++b;
+    return (int32_t)(((uint64_t)b * (uint64_t)n_events + kFrBucketsC - 1) / kFrBucketsC); // smallest c with bucket(c) >= b
 }
 
 int fr_slab_rows_for(int32_t n_events) {
@@ -94,10 +117,28 @@ __device__ __forceinline__ unsigned fr_chunk_slot(unsigned pos) {
     return (pos - p) + ((p & 63u) << 2) + (p >> 6);
 }
 
+// chunks per (slab, part) when the columns are cut into H > 1 parts: one workgroup per slab counts its entries per part
+__global__ __launch_bounds__(256) void k_fr_count_chunks_parts(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                                               int64_t n_rows, int32_t n_events, int slab_rows, int H,
+                                                               int64_t* __restrict__ chunks /* [n_slabs * H] */) {
+    __shared__ unsigned cnt[kQ8MaxParts];
+    const int64_t s = blockIdx.x;
+    const int64_t r0 = s * slab_rows;
+    const int64_t r1 = r0 + slab_rows < n_rows ? r0 + slab_rows : n_rows;
+    if (threadIdx.x < kQ8MaxParts) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256)
+        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k)
+            atomicAdd(&cnt[fr_part_of_bucket(fr_bucket_of((uint32_t)col_idx[k], (uint64_t)n_events), H)], 1u);
+    __syncthreads();
+    if ((int)threadIdx.x < H) chunks[s * H + threadIdx.x] = (int64_t)((cnt[threadIdx.x] + kFrChunk - 1) / kFrChunk);
+}
+
 __global__ __launch_bounds__(256) void k_fr_build_sorted(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
-                                                         int64_t n_rows, int32_t n_events, int slab_rows, int row_bits,
+                                                         int64_t n_rows, int32_t n_events, int slab_rows, int row_bits, int H,
                                                          const int64_t* __restrict__ fr_off, uint32_t* __restrict__ stream) {
     __shared__ unsigned hist[kFrBuckets + 1];
+    __shared__ unsigned ps[kQ8MaxParts + 1]; // first (unpadded) sorted slot of each part; ps[H] = the slab's entries
     const int64_t s = blockIdx.x;
     const int64_t r0 = s * slab_rows;
     const int64_t r1 = r0 + slab_rows < n_rows ? r0 + slab_rows : n_rows;
@@ -123,22 +164,33 @@ __global__ __launch_bounds__(256) void k_fr_build_sorted(const int64_t* __restri
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const unsigned c = loc[i]; hist[1 + tid * 8 + i] = run; run += c; }
     }
+    const int64_t nnz = row_ptr[r1] - row_ptr[r0];
+    if (tid <= H) { // where each part starts in the sorted order (before the cursors move)
+        unsigned b = 0;
+        while (b < (unsigned)kFrBuckets && fr_part_of_bucket(b, H) < tid) ++b;
+        ps[tid] = tid == H ? (unsigned)nnz : hist[1 + b];
+    }
     __syncthreads();
-    // hist[1 + b] is now the cursor of bucket b
-    uint32_t* out = stream + fr_off[s] * kFrChunk;
+    // hist[1 + b] is now the cursor of bucket b; part h of the slab starts at chunk fr_off[s * H + h]
+    uint32_t* out = stream + fr_off[s * H] * kFrChunk;
     for (int64_t r = r0 + tid; r < r1; r += 256)
         for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
             const uint32_t c = (uint32_t)col_idx[k];
-            const unsigned pos = atomicAdd(&hist[(unsigned)(((uint64_t)c * nb) / ne) + 1u], 1u);
-            out[fr_chunk_slot(pos)] = (c << row_bits) | (uint32_t)(r - r0);
+            const unsigned b = (unsigned)(((uint64_t)c * nb) / ne);
+            const unsigned pos = atomicAdd(&hist[b + 1u], 1u);
+            const int h = fr_part_of_bucket(b, H);
+            const unsigned idx = (unsigned)((fr_off[s * H + h] - fr_off[s * H]) * kFrChunk) + (pos - ps[h]);
+            out[fr_chunk_slot(idx)] = (c << row_bits) | (uint32_t)(r - r0);
         }
-    const int64_t nnz = row_ptr[r1] - row_ptr[r0];
-    const int64_t padded = (nnz + kFrChunk - 1) / kFrChunk * kFrChunk;
-    // padding: col 0 -> one of the 64 sink rows, chosen so that the 64 lanes of one LDS add hit 64 DIFFERENT slots
-    // (64 atomics on one address serialise: a padded chunk then costs more than a real one)
-    for (int64_t i = nnz + tid; i < padded; i += 256) {
-        const unsigned ph = fr_chunk_slot((unsigned)i);
-        out[ph] = (uint32_t)slab_rows + ((ph >> 2) & 63u);
+    // padding of every part: col 0 -> one of the 64 sink rows, chosen so that the 64 lanes of one LDS add hit 64
+    // DIFFERENT slots (64 atomics on one address serialise: a padded chunk then costs more than a real one)
+    for (int h = 0; h < H; ++h) {
+        const unsigned base = (unsigned)((fr_off[s * H + h] - fr_off[s * H]) * kFrChunk), n_h = ps[h + 1] - ps[h];
+        const unsigned padded = (n_h + kFrChunk - 1) / kFrChunk * kFrChunk;
+        for (unsigned i = n_h + tid; i < padded; i += 256) {
+            const unsigned ph = fr_chunk_slot(base + i);
+            out[ph] = (uint32_t)slab_rows + ((ph >> 2) & 63u);
+        }
     }
 }
 
@@ -406,6 +458,121 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
     if (tid == 0 && n_cand) atomicAdd(cand_count, n_cand); // one global atomic per workgroup, as in k_fr_filter
 }
 
+// ---- pass A, quantised form, wide event spaces (112 K < E <= 2^18): one part of the table resident per sweep ----
+struct Q8Parts {
+    int H;
+    int32_t c_lo[kQ8MaxParts + 1]; // first column of part h; c_lo[H] = n_events
+};
+
+template <int U>
+__global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8p(const uint4* __restrict__ stream, const int64_t* __restrict__ fr_off,
+                                                              int64_t total_chunks, const uint8_t* __restrict__ q8, Q8Parts P,
+                                                              int64_t n_rows, int64_t n_slabs, int threshold,
+                                                              uint16_t* __restrict__ cand_list, unsigned* __restrict__ cand_cnt,
+                                                              unsigned long long* __restrict__ cand_count, size_t tab_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* sums = reinterpret_cast<unsigned*>(smem);
+    uint8_t* tab = reinterpret_cast<uint8_t*>(smem + kQ8SumsBytes);
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(smem + kQ8SumsBytes + tab_bytes); // [128]
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int64_t G = (int64_t)gridDim.x;
+    const int H = P.H;
+    constexpr int NI = kQ8SlabRows / kQ8Threads;
+    uint4 q[U];
+    for (int i = tid; i < kQ8SlabRows + 64; i += kQ8Threads) sums[i] = 0u;
+    unsigned long long n_cand = 0;
+    for (int h = 0; h < H; ++h) {
+        const int a0 = P.c_lo[h] & ~15, a1 = P.c_lo[h + 1]; // the table bytes of this part (16-byte aligned start)
+#define FRP_FIRST_CHUNKS(SLAB)                                                                      \
+        if ((SLAB) < n_slabs) {                                                                     \
+            const int64_t f0 = fr_uload(fr_off + (SLAB) * H + h), f1 = fr_uload(fr_off + (SLAB) * H + h + 1); \
+            _Pragma("unroll") for (int u = 0; u < U; ++u) {                                         \
+                const int64_t c = f0 + wave + (int64_t)u * kQ8Waves;                                \
+                q[u] = stream[(c < f1 ? c : total_chunks) * kWave + lane];                          \
+            }                                                                                       \
+        }
+        FRP_FIRST_CHUNKS((int64_t)blockIdx.x)
+        fr_barrier(); // everybody is done with the previous part's table
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(q8 + a0);
+            uint4* dst = reinterpret_cast<uint4*>(tab);
+            for (int i = tid; i < (a1 - a0 + 15) / 16; i += kQ8Threads) dst[i] = src[i];
+        }
+        fr_barrier();
+        for (int64_t s = (int64_t)blockIdx.x; s < n_slabs; s += G) {
+            const int64_t c0 = fr_uload(fr_off + s * H + h), c1 = fr_uload(fr_off + s * H + h + 1);
+            uint16_t* part_sums = cand_list + s * kQ8SlabRows; // this slab's row sums between two sweeps (its list comes last)
+            if (h > 0) { // resume: the sums of the earlier parts (added, not stored: other waves may already be adding)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int rl = i * kQ8Threads + tid;
+                    __hip_atomic_fetch_add(&sums[rl], (unsigned)part_sums[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * kQ8Waves) {
+                uint4 qn[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t c = cb + (int64_t)(U + u) * kQ8Waves;
+                    qn[u] = stream[(c < c1 ? c : total_chunks) * kWave + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                    unsigned v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int col = (int)(e[k] >> kQ8RowBits);
+                        v[k] = tab[col >= a0 ? col - a0 : 0]; // (padding entries carry column 0 and a sink row)
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        __hip_atomic_fetch_add(&sums[e[k] & kQ8RowMask], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) q[u] = qn[u];
+            }
+            FRP_FIRST_CHUNKS(s + G)
+            fr_barrier();
+            const int64_t r0 = s * kQ8SlabRows;
+            if (h + 1 < H) { // not the last part: park the sums (saturated: 65535 is above every threshold)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int rl = i * kQ8Threads + tid;
+                    const unsigned sv = sums[rl];
+                    sums[rl] = 0u;
+                    part_sums[rl] = (uint16_t)(sv < 65535u ? sv : 65535u);
+                }
+                if (tid < 64) sums[kQ8SlabRows + tid] = 0u; // the sink
+                fr_barrier();
+                continue;
+            }
+            unsigned long long m[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int rl = i * kQ8Threads + tid;
+                const int sv = (int)sums[rl];
+                sums[rl] = 0u;
+                m[i] = __ballot(r0 + rl < n_rows && sv <= threshold);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) s_cnt[i * kQ8Waves + wave] = (unsigned)__builtin_popcountll(m[i]);
+            }
+            if (tid < 64) sums[kQ8SlabRows + tid] = 0u; // the sink
+            fr_barrier();
+            const unsigned no_flags[NI] = {};
+            const unsigned total = fr_emit_candidates<NI, kQ8Waves>(m, no_flags, s_cnt, lane, wave, tid, cand_list + s * kQ8SlabRows);
+            if (tid == 0) cand_cnt[s] = total;
+            n_cand += total; // workgroup-uniform
+        }
+#undef FRP_FIRST_CHUNKS
+    }
+    if (tid == 0 && n_cand) atomicAdd(cand_count, n_cand);
+}
+
 // ---- pass B ------------------------------------------------------------------------------------------
 // Two waves per slab walk its candidate list, 64 candidates per trip each: a lane sums one candidate row
 // from the canonical CSR in CSR order. Fixed wave <- (slab, half) and lane <- list position assignment =>
@@ -518,6 +685,7 @@ struct FxScalars {
     long long f_smax;   // F > f_smax: the sum's own error bound exceeds the budget (or an entry was clamped) -> exact pass
     int32_t L;          // max_row_len (bounded by limit_order when that is smaller)
     int32_t limit_order, need_len;
+    int32_t H;          // column parts of the stream: slab s holds chunks [fr_off[s * H], fr_off[(s + 1) * H])
 };
 
 template <int SLAB_ROWS, int WAVES, int U, bool TABLE_LDS>
@@ -541,7 +709,7 @@ __global__ __launch_bounds__(WAVES * kWave) void k_fx_sum(const uint4* __restric
     uint4 q[U];
 #define FX_FIRST_CHUNKS(SLAB)                                                                       \
     if ((SLAB) < sc.n_slabs) {                                                                      \
-        const int64_t f0 = fr_uload(fr_off + (SLAB)), f1 = fr_uload(fr_off + (SLAB) + 1);           \
+        const int64_t f0 = fr_uload(fr_off + (SLAB) * sc.H), f1 = fr_uload(fr_off + ((SLAB) + 1) * sc.H); \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                             \
             const int64_t c = f0 + wave + (int64_t)u * WAVES;                                       \
             q[u] = stream[(c < f1 ? c : sc.total_chunks) * kWave + lane];                           \
@@ -559,7 +727,7 @@ __global__ __launch_bounds__(WAVES * kWave) void k_fx_sum(const uint4* __restric
     FxAcc acc = {{0.0, 0.0}, {0.0, 0.0}, 0.0, 0.0};
     unsigned long long n_cand = 0;
     for (int64_t s = (int64_t)blockIdx.x; s < sc.n_slabs; s += G) {
-        const int64_t c0 = fr_uload(fr_off + s), c1 = fr_uload(fr_off + s + 1);
+        const int64_t c0 = fr_uload(fr_off + s * sc.H), c1 = fr_uload(fr_off + (s + 1) * sc.H);
         // -------- phase 1: any wave, any chunk: table value, unordered exact LDS add
         for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * WAVES) {
             unsigned long long v[U][4];
@@ -741,7 +909,7 @@ __global__ __launch_bounds__(kFx2Waves * kWave) void k_fx2(const uint4* __restri
     uint4 q[U], q2[U];
 #define FX2_FIRST_CHUNKS(SLAB)                                                                      \
     if ((SLAB) < sc.n_slabs) {                                                                      \
-        const int64_t f0 = fr_uload(fr_off + (SLAB)), f1 = fr_uload(fr_off + (SLAB) + 1);           \
+        const int64_t f0 = fr_uload(fr_off + (SLAB) * sc.H), f1 = fr_uload(fr_off + ((SLAB) + 1) * sc.H); \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                             \
             const int64_t c = f0 + wave + (int64_t)u * ADD;                                         \
             q[u] = stream[(c < f1 ? c : sc.total_chunks) * kWave + lane];                           \
@@ -766,7 +934,7 @@ __global__ __launch_bounds__(kFx2Waves * kWave) void k_fx2(const uint4* __restri
         if (adder) {
             if (have) { // -------- add slab s into buffer it & 1: any adding wave, any chunk
                 unsigned long long* sums = bufs + (size_t)(it & 1) * kBuf;
-                const int64_t c0 = fr_uload(fr_off + s), c1 = fr_uload(fr_off + s + 1);
+                const int64_t c0 = fr_uload(fr_off + s * sc.H), c1 = fr_uload(fr_off + (s + 1) * sc.H);
                 // two register sets in ping-pong (a copy "q = qn" at the end of the body makes the compiler wait for all
                 // of the next chunks every iteration)
 #define FX2_HALF(QC, QN, CB)                                                                                        \
@@ -966,25 +1134,29 @@ bool fr_filter_is_quantised(int32_t n_events) { return fr_use_q8(n_events) && fr
 int fr_refine_grid(int n_cu) { return n_cu * 8; }
 int fr_slab_rows(int32_t n_events) { return fr_slab_rows_for(n_events); }
 
-// Chunk offsets of the slabs (ceil(nnz_slab / 256) chunks each), shared by both stream forms.
-hipError_t fr_offsets(const int64_t* d_row_ptr, int64_t n_rows, int32_t n_events, int64_t** d_fr_off_out,
-                      int64_t* total_chunks_out, int64_t* n_slabs_out, bool* ok, hipStream_t s) {
+// Chunk offsets of the (slab, part) pairs: fr_off[s * H + h], H = fr_parts_for(n_events) (1 up to 112 K events).
+hipError_t fr_offsets(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events,
+                      int64_t** d_fr_off_out, int64_t* total_chunks_out, int64_t* n_slabs_out, bool* ok, hipStream_t s) {
     *ok = false;
     if (n_events > fr_max_events() || n_events < 1) return hipSuccess;
-    const int slab_rows = fr_slab_rows_for(n_events);
-    const int64_t n_slabs = (n_rows + slab_rows - 1) / slab_rows;
+    const int slab_rows = fr_slab_rows_for(n_events), H = fr_parts_for(n_events);
+    const int64_t n_slabs = (n_rows + slab_rows - 1) / slab_rows, n_off = n_slabs * H;
     *n_slabs_out = n_slabs;
     int64_t* d_off = nullptr;
-    hipError_t e = hipMalloc(&d_off, sizeof(int64_t) * (size_t)(n_slabs + 1));
+    hipError_t e = hipMalloc(&d_off, sizeof(int64_t) * (size_t)(n_off + 1));
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(d_off, 0, sizeof(int64_t), s);
     int64_t total = 0;
     if (e == hipSuccess && n_slabs > 0) {
-        hipLaunchKernelGGL(k_fr_count_chunks, dim3(grid_for(n_slabs, 256)), dim3(256), 0, s, d_row_ptr, n_rows, slab_rows, n_slabs,
-                           d_off + 1);
+        if (H == 1)
+            hipLaunchKernelGGL(k_fr_count_chunks, dim3(grid_for(n_slabs, 256)), dim3(256), 0, s, d_row_ptr, n_rows, slab_rows, n_slabs,
+                               d_off + 1);
+        else
+            hipLaunchKernelGGL(k_fr_count_chunks_parts, dim3((unsigned)n_slabs), dim3(256), 0, s, d_row_ptr, d_col_idx, n_rows, n_events,
+                               slab_rows, H, d_off + 1);
         e = hipGetLastError();
-        if (e == hipSuccess) e = scan_inclusive_i64(d_off + 1, n_slabs, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(&total, d_off + n_slabs, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = scan_inclusive_i64(d_off + 1, n_off, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, d_off + n_off, sizeof(int64_t), hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { (void)hipFree(d_off); return e; }
@@ -994,7 +1166,7 @@ hipError_t fr_offsets(const int64_t* d_row_ptr, int64_t n_rows, int32_t n_events
     return hipSuccess;
 }
 
-// The column-bucket-sorted 32-bit stream both filters read.
+// The column-bucket-sorted 32-bit stream all slab passes read.
 hipError_t fr_build_sorted32(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events,
                              const int64_t* d_fr_off, int64_t total_chunks, int64_t n_slabs, uint32_t** d_stream_out,
                              hipStream_t s) {
@@ -1005,7 +1177,7 @@ hipError_t fr_build_sorted32(const int64_t* d_row_ptr, const int32_t* d_col_idx,
     hipLaunchKernelGGL(k_fr_fill, dim3(1), dim3(256), 0, s, d_stream + total_chunks * kFrChunk, (int64_t)kFrChunk, (uint32_t)slab_rows); // the no-op chunk
     if (n_slabs > 0) {
         hipLaunchKernelGGL(k_fr_build_sorted, dim3((unsigned)n_slabs), dim3(256), 0, s, d_row_ptr, d_col_idx, n_rows, n_events,
-                           slab_rows, row_bits, d_fr_off, d_stream);
+                           slab_rows, row_bits, fr_parts_for(n_events), d_fr_off, d_stream);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -1013,6 +1185,8 @@ hipError_t fr_build_sorted32(const int64_t* d_row_ptr, const int32_t* d_col_idx,
     *d_stream_out = d_stream;
     return hipSuccess;
 }
+
+int fr_parts(int32_t n_events) { return fr_parts_for(n_events); }
 
 namespace {
 template <int SLAB_ROWS, int U>
@@ -1069,6 +1243,35 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
     }
     static const int u = getenv("CANOPY_FR_QU") ? atoi(getenv("CANOPY_FR_QU")) : 4; // tuning only (chunks in flight per wave)
     static const int fr_dbg = getenv("CANOPY_FR_DEBUG") ? atoi(getenv("CANOPY_FR_DEBUG")) : 0; // timing ablations only
+    const int H = fr_parts_for(n_events);
+    if (H > 1) { // wide event space: one part of the table resident per sweep
+        Q8Parts P;
+        P.H = H;
+        size_t part_max = 0;
+        for (int h = 0; h <= H; ++h) P.c_lo[h] = fr_part_first_col(h, H, n_events);
+        for (int h = 0; h < H; ++h) {
+            const size_t bytes = (size_t)(P.c_lo[h + 1] - (P.c_lo[h] & ~15) + 15) / 16 * 16;
+            part_max = bytes > part_max ? bytes : part_max;
+        }
+        const size_t lds_p = kQ8SumsBytes + part_max + (kQ8SlabRows / 64) * 4;
+        if (lds_p > (size_t)160 * 1024) return hipErrorInvalidValue;
+        int64_t gp = n_cu;
+        if (gp > n_slabs) gp = n_slabs;
+        if (gp < 1) gp = 1;
+#define Q8P_GO(UU)                                                                                                     \
+        do {                                                                                                           \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8p<UU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return e;                                                                             \
+            hipLaunchKernelGGL(k_fr_filter_q8p<UU>, dim3((unsigned)gp), dim3(kQ8Threads), lds_p, s, reinterpret_cast<const uint4*>(stream), \
+                               fr_off, total_chunks, q8_buf, P, n_rows, n_slabs, threshold, cand_list, cand_cnt, cand_count, part_max); \
+            return hipGetLastError();                                                                                  \
+        } while (0)
+        if (u == 2) Q8P_GO(2);
+        if (u == 3) Q8P_GO(3);
+        if (u == 6) Q8P_GO(6);
+        Q8P_GO(4);
+#undef Q8P_GO
+    }
     const size_t lds = kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16 + (kQ8SlabRows / 64) * 4;
     const void* fn = u == 1   ? reinterpret_cast<const void*>(&k_fr_filter_q8<1>)
                      : u == 2 ? reinterpret_cast<const void*>(&k_fr_filter_q8<2>)
@@ -1176,6 +1379,7 @@ hipError_t launch_fx_sum(const uint32_t* stream, const int64_t* fr_off, int64_t 
                          unsigned* cand_cnt, unsigned long long* cand_count, uint64_t* keep_mask, int grid, hipStream_t s) {
     FxScalars sc;
     sc.total_chunks = total_chunks; sc.n_rows = n_rows; sc.n_slabs = n_slabs;
+    sc.H = fr_parts_for(n_events);
     sc.limit_order = limit_order;
     sc.need_len = (limit_order != 0 && limit_order < max_row_len) ? 1 : 0;
     int L = max_row_len;

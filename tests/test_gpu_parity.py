@@ -247,11 +247,14 @@ def test_config3_full_size_properties(gpu_ctx, oracle):
     assert part_whole.n_kept == whole.n_kept
 
 
-def test_filter_refine_wide_event_space(gpu_ctx, oracle):
-    """E > 2^17 switches the filter/refine stream to 8192-row slabs (14 row bits, 18 column bits)."""
-    n_events = 200000
+@pytest.mark.parametrize("n_events", [114_689, 200_000, 229_376, 229_377, 262_144])
+def test_filter_refine_wide_event_space(gpu_ctx, oracle, n_events):
+    """Beyond 112 K events the 8-bit filter table is cut into 2 or 3 column parts, one resident per sweep, the row sums
+    carried between sweeps (114 689 = first size with two parts, 229 376 = last with two, 2^18 = the largest event space
+    of the slab stream: 18 column bits). Every variant against the oracle, FILTER_REFINE and FIXED_SUM included."""
     row_ptr, col = oracle.synth_csr(SEED, 300000, n_events, 6, n_threads=4)
     p = oracle.synth_probabilities(SEED, n_events)
+    p[::7] = np.minimum(1.0, p[::7] * 3e3)  # some likely events: candidates with entries in every part
     check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, 1e-10, 20, threads=4)
 
 
