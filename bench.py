@@ -127,8 +127,8 @@ def main():
     ap.add_argument("--shard-of", type=int, default=0,
                     help="single-GPU rehearsal of a strong-scaling shard: run shard 0 of an N-way split of --rows")
     ap.add_argument("--rehearse-backend", default="",
-                    help="rehearsal only: torch collective over this backend (gloo) with every rank on GPU "
-                         "LOCAL_RANK %% device_count -- lets a one-GPU box run the N>1 code path")
+                    help="rehearsal only: every rank on GPU LOCAL_RANK %% device_count (a one-GPU box running the N>1 code "
+                         "path); the torch fallback collective then uses this backend (gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearse the N>1 code path (communicator, gather slots, all-reduce) at world size 1")
     args = ap.parse_args()
@@ -145,9 +145,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the quantification path")
-    if args.rehearse_backend:
-        local_rank = local_rank % torch.cuda.device_count()
-        args.collective = "torch"
+    if args.rehearse_backend:  # several ranks on one GPU: the library's communicator is still tried first (RCCL may refuse
+        local_rank = local_rank % torch.cuda.device_count()  # duplicate devices: then the fallback below is what is rehearsed)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -222,9 +221,21 @@ def main():
             torch.cuda.synchronize()
 
     ctx.set_pipeline(not args.no_pipeline)
-    for _ in range(args.spinup):  # setup, like the model build: not a warm-up step, not timed
-        step()
-    ctx.synchronize()
+    pipeline_note = ""
+    try:
+        for _ in range(args.spinup):  # setup, like the model build: not a warm-up step, not timed
+            step()
+        ctx.synchronize()
+    except canopy_amd._capi.CanopyError as e:  # e.g. an RCCL that refuses calls from several streams: serial passes instead
+        if args.no_pipeline:
+            raise
+        sys.stderr.write("[bench] pipelined spin-up failed (%r): continuing with serial passes\n" % (e,))
+        pipeline_note = "pipelining switched off after %r" % (e,)
+        args.no_pipeline = True
+        ctx.set_pipeline(False)
+        for _ in range(args.spinup):
+            step()
+        ctx.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
@@ -355,7 +366,7 @@ def main():
                 "serial_pass_ms_note": "pass = row kernels + final reduce (+ all-reduce at N > 1), one pass at a time",
                 "host_enqueue_ms_per_step": t_enqueued * 1e3 / args.steps,
                 "last_collective_ms": collective_ms,
-                "pipelined": not args.no_pipeline,
+                "pipelined": not args.no_pipeline, "pipeline_note": pipeline_note or None,
                 "probe": "kernel / pass ms: %d instrumented serial passes after the timed region" % n_timed,
             },
             "result": {"rare_event": result.rare_event, "mcub": result.mcub, "n_kept": result.n_kept,

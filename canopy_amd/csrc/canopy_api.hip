@@ -51,7 +51,7 @@ canopy_status ensure_block_partials(canopy_ctx* ctx, canopy_ctx::PassScratch& S,
     S.block_partials_cap = 0;
     HIP_TRY(ctx, hipMalloc(&S.d_block_partials, sizeof(double) * kAccDoubles * (size_t)grid));
     S.block_partials_cap = grid;
-    ++ctx->scratch_gen; // captured passes hold the old pointer
+    if (&S == &ctx->sets[0]) ++ctx->scratch_gen; // captured passes (always lane 0) hold the old pointer
     return CANOPY_OK;
 }
 
@@ -85,7 +85,7 @@ void free_model_buffers(canopy_model* m) {
 } // namespace
 
 hipError_t canopy::ctx_join_side(canopy_ctx* ctx) {
-    for (int k = 1; k < canopy_ctx::kLanes; ++k) { // lane 0 IS the context's stream
+    for (int k = 0; k < canopy_ctx::kLanes; ++k) { // (lane 0 IS the context's stream: pending only behind a collective)
         canopy_ctx::PassScratch& S = ctx->sets[k];
         if (!S.pending) continue;
         hipError_t e = hipStreamWaitEvent(ctx->stream, S.ev_done, 0);
@@ -620,9 +620,10 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         st = join_side(ctx);
         if (st != CANOPY_OK) return st;
     } else if (S.used) {
-        // the lane's previous pass must have finished: back-pressure on the HOST (it stays up to two passes ahead of the
-        // device), not a wait in a device queue
+        // the lane's previous pass (its collective included) must have finished: back-pressure on the HOST (it stays up to
+        // two passes ahead of the device), not a wait in a device queue
         HIP_TRY(ctx, hipEventSynchronize(S.ev_done));
+        S.pending = false;
     }
     hipStream_t lane = S.stream; // every launch of this pass
     double* const d_gather = S.d_gather ? S.d_gather : ctx->d_gather;
@@ -675,14 +676,14 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             if (S.d_fr_list) (void)hipFree(S.d_fr_list);
             S.d_fr_list = nullptr; S.fr_list_cap = 0;
             HIP_TRY(ctx, hipMalloc(&S.d_fr_list, sizeof(uint16_t) * (size_t)(list_len > 0 ? list_len : 1)));
-            S.fr_list_cap = list_len; ++ctx->scratch_gen;
+            S.fr_list_cap = list_len; if (set == 0) ++ctx->scratch_gen;
         }
         const int64_t cnt_need = m->n_fr_slabs * 8; // the fixed-point pass keeps up to eight list units per slab
         if (S.fr_cnt_cap < cnt_need || !S.d_fr_cnt) {
             if (S.d_fr_cnt) (void)hipFree(S.d_fr_cnt);
             S.d_fr_cnt = nullptr; S.fr_cnt_cap = 0;
             HIP_TRY(ctx, hipMalloc(&S.d_fr_cnt, sizeof(unsigned) * (size_t)(cnt_need > 0 ? cnt_need : 1)));
-            S.fr_cnt_cap = cnt_need; ++ctx->scratch_gen;
+            S.fr_cnt_cap = cnt_need; if (set == 0) ++ctx->scratch_gen;
         }
         if (want_mask && variant == CANOPY_KERNEL_FILTER_REFINE && !ctx->filter_only_request) // the refine pass ORs the exact keep bits into a cleared mask
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
@@ -758,17 +759,19 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
                                  ctx->gather_rank, two_step ? S.d_fr_count : nullptr, lane));
     ctx->last_variant = variant;
     ctx->last_set = set;
+    hipStream_t last = lane; // the stream the pass ends on
     if (ctx->comm) { // K5: the one collective of the path, issued here (not by the host language), behind the final reduce
-        canopy_status cst = comm_all_reduce_partials(ctx, lane, d_gather);
+        canopy_status cst = comm_all_reduce_partials(ctx, lane, d_gather, set);
         if (cst != CANOPY_OK) return cst;
+        if (comm_stream(ctx)) last = comm_stream(ctx);
     }
-    if (timed) HIP_TRY(ctx, hipEventRecord(ev[2], lane));
-    if (pipelined) {
-        HIP_TRY(ctx, hipEventRecord(S.ev_done, lane));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ev[2], last));
+    if (pipelined || last != lane) { // someone has to wait for this pass later: the lane's next pass, a fetch, a join
+        HIP_TRY(ctx, hipEventRecord(S.ev_done, last));
         S.used = true;
-        S.pending = set != 0;
-        ctx->pipe_next = (set + 1) % canopy_ctx::kLanes;
+        S.pending = set != 0 || last != lane;
     }
+    if (pipelined) ctx->pipe_next = (set + 1) % canopy_ctx::kLanes;
     if (want_imp) { // after the timed pass: one walk over the kept rows
         double* dst = ctx->ext_importance ? ctx->ext_importance : ctx->d_importance;
         HIP_TRY(ctx, hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(m->n_events > 0 ? m->n_events : 1), ctx->stream));

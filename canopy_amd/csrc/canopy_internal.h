@@ -114,6 +114,10 @@ struct canopy_comm {
     int world = 1, rank = 0;
     double* d_buf = nullptr; // [lanes][world][8] gather slots = the all-reduce buffers, one per lane of the context
     double* h_buf = nullptr; // pinned mirror
+    // CANOPY_COMM_OWN_STREAM=1 only: every collective is enqueued on `stream`, behind an event of the lane whose final
+    // reduce filled the buffer (default: null, the collective rides the lane; RCCL orders calls from different streams)
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_lane[canopy_ctx::kLanes] = {nullptr, nullptr, nullptr}; // "this lane's record is in its slot buffer"
     hipEvent_t ev_fin = nullptr, ev_done = nullptr; // around the last all-reduce (timing)
     bool issued = false;
     double* last_buf = nullptr; // slot buffer of the last issued collective
@@ -220,7 +224,8 @@ hipError_t synth_build_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int
 
 // comm_rccl.hip
 // the single collective of a pass, enqueued on the stream its final reduce ran on
-canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t stream, double* buf);
+canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane);
+hipStream_t comm_stream(canopy_ctx* ctx);
 // orders the context's stream behind everything enqueued on the other lanes (device-side waits, no host blocking)
 hipError_t ctx_join_side(canopy_ctx* ctx);
 canopy_status comm_all_reduce_mc(canopy_ctx* ctx, const unsigned long long* d_hits, long long trials);

@@ -107,6 +107,8 @@ void comm_release(canopy_comm* c) { // device / host resources only (not the RCC
     if (c->h_mc) (void)hipHostFree(c->h_mc);
     if (c->ev_fin) (void)hipEventDestroy(c->ev_fin);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    for (auto e : c->ev_lane) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -120,6 +122,13 @@ canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, ca
     if (e == hipSuccess) e = hipHostMalloc(&c->h_buf, bytes);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_fin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_done);
+    // CANOPY_COMM_OWN_STREAM=1: every collective on ONE stream of the communicator's own, behind an event of the pass's
+    // lane (two cross-queue edges per pass: ~17 us at the shard size of an 8-GPU run). Default: the collective goes straight
+    // onto the lane that ran the final reduce; consecutive passes then call RCCL from different streams, which RCCL orders
+    // itself (its launches are chained through the communicator's internal device stream).
+    static const bool own_stream = getenv("CANOPY_COMM_OWN_STREAM") != nullptr;
+    if (e == hipSuccess && own_stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int k = 0; k < canopy_ctx::kLanes && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->ev_lane[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_mc, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_mc, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_buf, 0, canopy_ctx::kLanes * bytes, ctx->stream);
@@ -141,28 +150,41 @@ canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, ca
 
 namespace canopy {
 
-// Called by canopy_quantify_async right behind k_finalize, on the pass's lane: buf = that lane's slot buffer. (When the
-// stream changes from one call to the next RCCL itself orders the new collective behind the previous one.)
-canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t stream, double* buf) {
+// Called by canopy_quantify_async right behind k_finalize: buf = the slot buffer of the pass's lane, lane_stream = the
+// stream its final reduce ran on. No host round trip.
+canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane) {
     canopy_comm* c = ctx->comm;
     if (!c || c->deferred) return CANOPY_OK;
-    HIPC_TRY(ctx, hipEventRecord(c->ev_fin, stream));
+    hipStream_t st = lane_stream;
+    if (c->stream) { // own-stream mode
+        HIPC_TRY(ctx, hipEventRecord(c->ev_lane[lane], lane_stream));
+        HIPC_TRY(ctx, hipStreamWaitEvent(c->stream, c->ev_lane[lane], 0));
+        st = c->stream;
+    }
+    HIPC_TRY(ctx, hipEventRecord(c->ev_fin, st));
     RCCL_TRY(ctx, rccl()->AllReduce(buf, buf, (size_t)c->world * CANOPY_PARTIAL_DOUBLES, ncclDouble, ncclSum,
-                                    static_cast<ncclComm_t>(c->comm), stream));
-    HIPC_TRY(ctx, hipEventRecord(c->ev_done, stream));
+                                    static_cast<ncclComm_t>(c->comm), st));
+    HIPC_TRY(ctx, hipEventRecord(c->ev_done, st));
     c->issued = true;
     c->last_buf = buf;
     return CANOPY_OK;
 }
 
+hipStream_t comm_stream(canopy_ctx* ctx) { return (ctx->comm && !ctx->comm->deferred) ? ctx->comm->stream : nullptr; } // null: collectives ride the lanes
+
 // K6: [hits, trials] of every rank summed (one u64 all-reduce of 2 words), same stream.
 canopy_status comm_all_reduce_mc(canopy_ctx* ctx, const unsigned long long* d_hits, long long trials) {
     canopy_comm* c = ctx->comm;
     if (!c || c->deferred) return CANOPY_OK; // one process, N devices: the host adds the N hit counts itself
-    HIPC_TRY(ctx, canopy::ctx_join_side(ctx)); // one communicator: its collectives stay in one stream order
     hipLaunchKernelGGL(k_mc_pack, dim3(1), dim3(1), 0, ctx->stream, c->d_mc, d_hits, (unsigned long long)trials);
     HIPC_TRY(ctx, hipGetLastError());
-    RCCL_TRY(ctx, rccl()->AllReduce(c->d_mc, c->d_mc, 2, ncclUint64, ncclSum, static_cast<ncclComm_t>(c->comm), ctx->stream));
+    hipStream_t st = ctx->stream;
+    if (c->stream) {
+        HIPC_TRY(ctx, hipEventRecord(c->ev_lane[0], ctx->stream)); // the communicator's own stream, behind the pack
+        HIPC_TRY(ctx, hipStreamWaitEvent(c->stream, c->ev_lane[0], 0));
+        st = c->stream;
+    }
+    RCCL_TRY(ctx, rccl()->AllReduce(c->d_mc, c->d_mc, 2, ncclUint64, ncclSum, static_cast<ncclComm_t>(c->comm), st));
     c->mc_valid = true;
     return CANOPY_OK;
 }
@@ -242,6 +264,7 @@ void canopy_comm_free(canopy_comm* c) {
             for (auto& S : ctx->sets) S.d_gather = nullptr;
         }
     }
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl()->handle) (void)rccl()->CommDestroy(static_cast<ncclComm_t>(c->comm));
     comm_release(c);
 }
@@ -322,8 +345,9 @@ canopy_status canopy_comm_mc_fetch(canopy_comm* c, canopy_mc_result* r) try {
     if (!c->mc_valid) return comm_fail(ctx, CANOPY_ERR_STATE, "no Monte-Carlo run since the communicator was attached");
     HIPC_TRY(ctx, hipSetDevice(ctx->device));
     unsigned long long host[2];
-    HIPC_TRY(ctx, hipMemcpyAsync(c->h_mc, c->d_mc, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
-    HIPC_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t st = c->stream ? c->stream : ctx->stream;
+    HIPC_TRY(ctx, hipMemcpyAsync(c->h_mc, c->d_mc, sizeof(host), hipMemcpyDeviceToHost, st));
+    HIPC_TRY(ctx, hipStreamSynchronize(st));
     host[0] = c->h_mc[0]; host[1] = c->h_mc[1];
     r->hits = (int64_t)host[0];
     r->num_trials = (int64_t)host[1];

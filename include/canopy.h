@@ -295,9 +295,12 @@ CANOPY_API canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* dev
  * Monte-Carlo (K6): with a communicator attached (process-per-GPU shape) canopy_mc_run_async also sums
  * {hits, trials} over the ranks (one u64 all-reduce); canopy_comm_mc_fetch returns the global estimate.
  * canopy_comm_free detaches (the context returns to single-shard behaviour); free it before its context.
- * Streams: the all-reduce is enqueued right behind the pass's final reduce, on the stream that ran it -- for a pipelined
- * pass (canopy_ctx_set_pipeline) its lane, so the next pass's row kernel streams while the (latency-bound) collective
- * of this one is on the wire. canopy_comm_fetch waits for the LAST enqueued pass.
+ * Streams: the all-reduce is enqueued right behind the pass's final reduce, on the lane that ran it
+ * (canopy_ctx_set_pipeline): the next pass's row kernel streams on another lane while the (latency-bound) collective
+ * of this one is on the wire. Consecutive passes therefore call RCCL from different streams; RCCL chains its launches
+ * through the communicator's internal stream. CANOPY_COMM_OWN_STREAM=1 in the environment instead gives the
+ * communicator ONE stream of its own, each collective behind an event of its lane (two cross-queue edges per pass).
+ * canopy_comm_fetch waits for the LAST enqueued pass.
  */
 #define CANOPY_COMM_ID_BYTES 128
 typedef struct canopy_comm_id { char bytes[CANOPY_COMM_ID_BYTES]; } canopy_comm_id;
