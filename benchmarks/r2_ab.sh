@@ -12,9 +12,9 @@ run() { # name, env..., -- args
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
 run e2e5 X=1 -- --no-also --events 200000 --steps 100
-run e2e5_u2 CANOPY_FR_QU=2 -- --no-also --events 200000 --steps 100
-run e2e5_u3 CANOPY_FR_QU=3 -- --no-also --events 200000 --steps 100
-run e2e5_u6 CANOPY_FR_QU=6 -- --no-also --events 200000 --steps 100
+run e262k X=1 -- --no-also --events 262144 --steps 100
+run c2 X=1 -- --no-also --rows 100000 --events 1000 --avg-nnz 4 --steps 1000
+run c2_nopipe X=1 -- --no-also --rows 100000 --events 1000 --avg-nnz 4 --steps 1000 --no-pipeline
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):

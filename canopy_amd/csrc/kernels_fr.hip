@@ -504,13 +504,11 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8p(const uint4* __res
         for (int64_t s = (int64_t)blockIdx.x; s < n_slabs; s += G) {
             const int64_t c0 = fr_uload(fr_off + s * H + h), c1 = fr_uload(fr_off + s * H + h + 1);
             uint16_t* part_sums = cand_list + s * kQ8SlabRows; // this slab's row sums between two sweeps (its list comes last)
-            if (h > 0) { // resume: the sums of the earlier parts (added, not stored: other waves may already be adding)
+            // resume: the sums of the earlier parts are requested now and ADDED after the chunk loop (adds commute; other
+            // waves may already be adding to these rows): their latency hides behind the slab's own work
+            unsigned resume[NI];
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int rl = i * kQ8Threads + tid;
-                    __hip_atomic_fetch_add(&sums[rl], (unsigned)part_sums[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
+            for (int i = 0; i < NI; ++i) resume[i] = h > 0 ? (unsigned)part_sums[i * kQ8Threads + tid] : 0u;
             for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * kQ8Waves) {
                 uint4 qn[U];
 #pragma unroll
@@ -535,6 +533,11 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8p(const uint4* __res
                 for (int u = 0; u < U; ++u) q[u] = qn[u];
             }
             FRP_FIRST_CHUNKS(s + G)
+            if (h > 0) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    __hip_atomic_fetch_add(&sums[i * kQ8Threads + tid], resume[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             fr_barrier();
             const int64_t r0 = s * kQ8SlabRows;
             if (h + 1 < H) { // not the last part: park the sums (saturated: 65535 is above every threshold)
