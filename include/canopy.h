@@ -464,6 +464,9 @@ CANOPY_API canopy_status canopy_dag_upload(canopy_ctx* ctx, const canopy_dag_vie
 CANOPY_API void canopy_dag_free(canopy_dag* dag);
 CANOPY_API canopy_status canopy_dag_set_probabilities(canopy_ctx* ctx, canopy_dag* dag, const double* p);
 
+/* (Settings::batch_size / sample_size, settings.h:129-151,326-327, exist in the reference as names with default 1 and no
+   stated meaning: a host that uses them as multipliers passes num_trials * batch_size * sample_size here. The sample
+   definition is counter-based, so a run may be cut into any number of calls by first_sample without changing a bit.) */
 typedef struct canopy_mc_params {
     uint64_t seed;        /* settings.h:324 */
     int64_t first_sample; /* global index of this shard's first sample, a multiple of 64 */
