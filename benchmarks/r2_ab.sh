@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 A/B runs on the GPU box (via gpurun): usage bash benchmarks/r2_ab.sh <tag>
 set -u
-TAG=${1:-ab}
+export TAG=${1:-ab}
 O=gpurun_out
 mkdir -p $O
 run() { # name, env..., -- args
@@ -11,16 +11,19 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run e2e5 X=1 -- --no-also --events 200000 --steps 100
-run e262k X=1 -- --no-also --events 262144 --steps 100
-run c2 X=1 -- --no-also --rows 100000 --events 1000 --avg-nnz 4 --steps 1000
-run c2_nopipe X=1 -- --no-also --rows 100000 --events 1000 --avg-nnz 4 --steps 1000 --no-pipeline
+run fx_12_4 X=1 -- --steps 60 --no-also --cut-off 0
+run fx_14_4 CANOPY_FX_ADD=14 CANOPY_FX_U=4 -- --steps 60 --no-also --cut-off 0
+run fx_8_4 CANOPY_FX_ADD=8 CANOPY_FX_U=4 -- --steps 60 --no-also --cut-off 0
+run fx_12_2 CANOPY_FX_U=2 -- --steps 60 --no-also --cut-off 0
+run fx_co1e-3 X=1 -- --steps 60 --no-also --cut-off 1e-3
+run fx_e5e4 X=1 -- --steps 60 --no-also --cut-off 0 --events 50000
+run fx_e2e5 X=1 -- --steps 60 --no-also --cut-off 0 --events 200000
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):
     try:
         j=json.load(open(f)); r=j["roofline"]
-        print(os.path.basename(f), "ms/step %.4f k_ms %.4f/%.4f pass %.4f frac %.3f kern %d" % (j["ms_per_step"], r["avg_kernel_ms"], r["min_kernel_ms"], r["avg_pass_ms"], r["frac"], j["config"]["kernel_ran"]), j["result"]["n_kept"], j["result"]["rare_event"], r.get("last_collective_ms"))
+        print(os.path.basename(f), "ms/step %.4f k_ms %.4f/%.4f pass %.4f frac %.3f kern %d" % (j["ms_per_step"], r["avg_kernel_ms"], r["min_kernel_ms"], r["avg_pass_ms"], r["frac"], j["config"]["kernel_ran"]), j["result"]["n_kept"], j["result"]["rare_event"], "prepare_s", j.get("model_prepare_s"), "also", j.get("also"))
     except Exception as e:
         print(f, "ERR", e)
 PY

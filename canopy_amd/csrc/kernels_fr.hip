@@ -97,6 +97,15 @@ int fr_slab_rows_for(int32_t n_events) {
 // (col 0 -> the sink row). Chunks are therefore narrow in column (what the 24-bit repacking and the gathered
 // fp64 filter both want), the stream is as dense as it can be, and the build is parallel.
 constexpr int kFrBuckets = 512;
+constexpr int kFrColHist = 576; // >= the columns of one bucket + 1 for E <= 2^18 (513), a multiple of 64
+
+// LDS traffic between the lanes of ONE wave (no workgroup barrier): the wave's LDS operations complete in order; this
+// keeps the compiler from moving them across
+__device__ __forceinline__ void fr_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __global__ __launch_bounds__(256) void k_fr_count_chunks(const int64_t* __restrict__ row_ptr, int64_t n_rows, int slab_rows,
                                                          int64_t n_slabs, int64_t* __restrict__ chunks) {
@@ -136,9 +145,11 @@ __global__ __launch_bounds__(256) void k_fr_count_chunks_parts(const int64_t* __
 
 __global__ __launch_bounds__(256) void k_fr_build_sorted(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
                                                          int64_t n_rows, int32_t n_events, int slab_rows, int row_bits, int H,
-                                                         const int64_t* __restrict__ fr_off, uint32_t* __restrict__ stream) {
+                                                         const int64_t* __restrict__ fr_off, uint32_t* __restrict__ tmp,
+                                                         uint32_t* __restrict__ stream) {
     __shared__ unsigned hist[kFrBuckets + 1];
     __shared__ unsigned ps[kQ8MaxParts + 1]; // first (unpadded) sorted slot of each part; ps[H] = the slab's entries
+    __shared__ unsigned chist[4][kFrColHist]; // phase 2: one wave's per-column counts of one bucket
     const int64_t s = blockIdx.x;
     const int64_t r0 = s * slab_rows;
     const int64_t r1 = r0 + slab_rows < n_rows ? r0 + slab_rows : n_rows;
@@ -173,15 +184,59 @@ __global__ __launch_bounds__(256) void k_fr_build_sorted(const int64_t* __restri
     __syncthreads();
     // hist[1 + b] is now the cursor of bucket b; part h of the slab starts at chunk fr_off[s * H + h]
     uint32_t* out = stream + fr_off[s * H] * kFrChunk;
+    uint32_t* tq = tmp + fr_off[s * H] * kFrChunk; // phase 1: bucket order, linear positions
     for (int64_t r = r0 + tid; r < r1; r += 256)
         for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
             const uint32_t c = (uint32_t)col_idx[k];
             const unsigned b = (unsigned)(((uint64_t)c * nb) / ne);
             const unsigned pos = atomicAdd(&hist[b + 1u], 1u);
-            const int h = fr_part_of_bucket(b, H);
-            const unsigned idx = (unsigned)((fr_off[s * H + h] - fr_off[s * H]) * kFrChunk) + (pos - ps[h]);
-            out[fr_chunk_slot(idx)] = (c << row_bits) | (uint32_t)(r - r0);
+            tq[pos] = (c << row_bits) | (uint32_t)(r - r0);
         }
+    __syncthreads(); // hist[b] .. hist[b + 1] is now bucket b's range of tq (hist[0] = 0); the slab's tq is complete
+    // phase 2: every bucket is sorted by COLUMN (a counting sort over its <= E/512 + 1 columns, one wave per bucket), so
+    // that the 64 lanes of one table-gather instruction of the gathered passes carry ascending addresses with
+    // neighbouring lanes in the same cache line: the texture addresser takes such an instruction in ~29 clocks instead
+    // of ~41 for the same lines in random lane order (benchmarks/microbench5.hip). Entries of one column keep an
+    // arbitrary order (no pass depends on it: integer sums commute, the fp64 filter is conservative by 1e-9).
+    {
+        const int wv = tid >> 6, lane = tid & (kWave - 1);
+        unsigned* ch = chist[wv];
+        for (unsigned b = (unsigned)wv; b < (unsigned)kFrBuckets; b += 4u) {
+            const unsigned lo = hist[b], hi = hist[b + 1u];
+            if (hi == lo) continue; // wave-uniform
+            const uint32_t c_lo = (uint32_t)(((uint64_t)b * ne + nb - 1) / nb), c_hi = (uint32_t)(((uint64_t)(b + 1u) * ne + nb - 1) / nb);
+            const unsigned n_cols = c_hi - c_lo; // <= kFrColHist - 1 (E <= 2^18)
+            for (unsigned i = (unsigned)lane; i < (unsigned)kFrColHist; i += kWave) ch[i] = 0u;
+            fr_wave_lds_sync();
+            for (unsigned p = lo + (unsigned)lane; p < hi; p += kWave) atomicAdd(&ch[(tq[p] >> row_bits) - c_lo], 1u);
+            fr_wave_lds_sync();
+            { // exclusive scan of the counts, kFrColHist / 64 per lane
+                constexpr int PER = kFrColHist / kWave;
+                unsigned loc[PER], tot = 0;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) { loc[i] = ch[lane * PER + i]; tot += loc[i]; }
+                unsigned incl = tot;
+#pragma unroll
+                for (int d = 1; d < kWave; d <<= 1) {
+                    const unsigned o = __shfl_up(incl, d, kWave);
+                    if (lane >= d) incl += o;
+                }
+                unsigned run = incl - tot;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) { const unsigned c = loc[i]; ch[lane * PER + i] = run; run += c; }
+            }
+            fr_wave_lds_sync();
+            const int h = fr_part_of_bucket(b, H);
+            const unsigned base = (unsigned)((fr_off[s * H + h] - fr_off[s * H]) * kFrChunk) - ps[h];
+            (void)n_cols;
+            for (unsigned p = lo + (unsigned)lane; p < hi; p += kWave) {
+                const uint32_t e = tq[p];
+                const unsigned q = lo + atomicAdd(&ch[(e >> row_bits) - c_lo], 1u);
+                out[fr_chunk_slot(base + q)] = e;
+            }
+            fr_wave_lds_sync();
+        }
+    }
     // padding of every part: col 0 -> one of the 64 sink rows, chosen so that the 64 lanes of one LDS add hit 64
     // DIFFERENT slots (64 atomics on one address serialise: a padded chunk then costs more than a real one)
     for (int h = 0; h < H; ++h) {
@@ -1174,16 +1229,21 @@ hipError_t fr_build_sorted32(const int64_t* d_row_ptr, const int32_t* d_col_idx,
                              const int64_t* d_fr_off, int64_t total_chunks, int64_t n_slabs, uint32_t** d_stream_out,
                              hipStream_t s) {
     const int slab_rows = fr_slab_rows_for(n_events), row_bits = slab_rows > 8192 ? 15 : 14;
+    if (n_events > (1 << 18)) return hipErrorInvalidValue; // 14 row bits + 18 column bits; kFrColHist
     uint32_t* d_stream = nullptr;
+    uint32_t* d_tmp = nullptr; // the slabs in bucket order, before the in-bucket column sort: build time only
     hipError_t e = hipMalloc(&d_stream, sizeof(uint32_t) * (size_t)((total_chunks + 1) * kFrChunk));
     if (e != hipSuccess) return e;
+    e = hipMalloc(&d_tmp, sizeof(uint32_t) * (size_t)((total_chunks + 1) * kFrChunk));
+    if (e != hipSuccess) { (void)hipFree(d_stream); return e; }
     hipLaunchKernelGGL(k_fr_fill, dim3(1), dim3(256), 0, s, d_stream + total_chunks * kFrChunk, (int64_t)kFrChunk, (uint32_t)slab_rows); // the no-op chunk
     if (n_slabs > 0) {
         hipLaunchKernelGGL(k_fr_build_sorted, dim3((unsigned)n_slabs), dim3(256), 0, s, d_row_ptr, d_col_idx, n_rows, n_events,
-                           slab_rows, row_bits, fr_parts_for(n_events), d_fr_off, d_stream);
+                           slab_rows, row_bits, fr_parts_for(n_events), d_fr_off, d_tmp, d_stream);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_tmp);
     if (e != hipSuccess) { (void)hipFree(d_stream); return e; }
     *d_stream_out = d_stream;
     return hipSuccess;
