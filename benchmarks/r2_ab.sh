@@ -11,13 +11,13 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run fx_12_4 X=1 -- --steps 60 --no-also --cut-off 0
-run fx_14_4 CANOPY_FX_ADD=14 CANOPY_FX_U=4 -- --steps 60 --no-also --cut-off 0
-run fx_8_4 CANOPY_FX_ADD=8 CANOPY_FX_U=4 -- --steps 60 --no-also --cut-off 0
-run fx_12_2 CANOPY_FX_U=2 -- --steps 60 --no-also --cut-off 0
-run fx_co1e-3 X=1 -- --steps 60 --no-also --cut-off 1e-3
-run fx_e5e4 X=1 -- --steps 60 --no-also --cut-off 0 --events 50000
-run fx_e2e5 X=1 -- --steps 60 --no-also --cut-off 0 --events 200000
+run d_u4 X=1 -- --steps 60 --no-also --no-pipeline
+run d_u4s CANOPY_FR_DSKIP=1 -- --steps 60 --no-also --no-pipeline
+run d_u2s CANOPY_FR_DSKIP=1 CANOPY_FR_DU=2 -- --steps 60 --no-also --no-pipeline
+run d_u3s CANOPY_FR_DSKIP=1 CANOPY_FR_DU=3 -- --steps 60 --no-also --no-pipeline
+run d_u6s CANOPY_FR_DSKIP=1 CANOPY_FR_DU=6 -- --steps 60 --no-also --no-pipeline
+run d_u1 CANOPY_FR_DU=1 -- --steps 60 --no-also --no-pipeline
+run d_u3 CANOPY_FR_DU=3 -- --steps 60 --no-also --no-pipeline
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):

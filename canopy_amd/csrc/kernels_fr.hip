@@ -487,7 +487,9 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
             for (int u = 0; u < U; ++u) q[u] = qn[u];
         }
         if (!(abl & 16)) { FR_FIRST_CHUNKS(s + G) } // the next slab's stream starts under this slab's end step
+        if (abl & 8) continue;                    // timing ablation (wrong results): no end step, no barrier
         fr_barrier();
+        if (abl & 4) continue;                    // timing ablation (wrong results): the barrier only
         const int64_t r0 = s * kQ8SlabRows;
         constexpr int NI = kQ8SlabRows / kQ8Threads;
         unsigned long long m[NI];

@@ -130,6 +130,27 @@ def test_gpu_mc_sample_shards_sum_to_whole(gpu_ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_mc_config5_full_size(gpu_ctx, oracle):
+    """BASELINE config 5 at its stated size: 1e9 samples through the benchmark's DAG (benchmarks/bench_mc.py), hits
+    bit-exact against the oracle on all host threads, and the 8 sample-range shards of an 8-GPU run add up to it."""
+    import os
+    from canopy_amd.quantifier import Dag
+    from canopy_amd.synthetic import layered_dag
+    dag = layered_dag(20250704, 100, 4, 250, 4, atleast_every=5)
+    p = np.random.default_rng(20250704).uniform(0.002, 0.1, 100)
+    d = Dag(gpu_ctx, dag)
+    d.set_probabilities(p)
+    n = 1_000_000_000
+    whole = d.run(SEED, n)
+    per = (n // 8) // 64 * 64
+    parts = [d.run(SEED, per if k < 7 else n - 7 * per, first_sample=k * per).hits for k in range(8)]
+    assert sum(parts) == whole.hits and whole.num_trials == n
+    want = oracle.mc(dag, p, SEED, n, n_threads=max(1, min(256, os.cpu_count() or 1)))
+    assert whole.hits == want, (whole.hits, want)
+    d.close()
+
+
+@pytest.mark.gpu
 def test_gpu_mc_rejects_bad_dags(gpu_ctx):
     from canopy_amd import _capi as c
     from canopy_amd.quantifier import Dag
