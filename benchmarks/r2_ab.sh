@@ -11,13 +11,8 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run d_u4 X=1 -- --steps 60 --no-also --no-pipeline
-run d_u4s CANOPY_FR_DSKIP=1 -- --steps 60 --no-also --no-pipeline
-run d_u2s CANOPY_FR_DSKIP=1 CANOPY_FR_DU=2 -- --steps 60 --no-also --no-pipeline
-run d_u3s CANOPY_FR_DSKIP=1 CANOPY_FR_DU=3 -- --steps 60 --no-also --no-pipeline
-run d_u6s CANOPY_FR_DSKIP=1 CANOPY_FR_DU=6 -- --steps 60 --no-also --no-pipeline
-run d_u1 CANOPY_FR_DU=1 -- --steps 60 --no-also --no-pipeline
-run d_u3 CANOPY_FR_DU=3 -- --steps 60 --no-also --no-pipeline
+run ws_sorted X=1 -- --steps 40 --no-also --no-pipeline --kernel 3 --cut-off 0
+run ws_unsorted CANOPY_WS_NOSORT=1 -- --steps 40 --no-also --no-pipeline --kernel 3 --cut-off 0
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):

@@ -283,6 +283,31 @@ __global__ __launch_bounds__(WsCfg<RW>::waves * kWave) void k_ws(const uint4* __
     }
 }
 
+// Post-pass of the builder: the 64 slots of every group re-ordered by column (a group holds 64 DISTINCT rows, so any
+// order inside it is the same arithmetic). One gather instruction of k_ws = one group: with ascending lane addresses,
+// neighbouring lanes in the same cache line, the texture addresser takes it in ~30 clocks instead of ~41
+// (benchmarks/microbench5.hip). One wave per chunk: a 64-lane bitonic sort per group (component of the lane's uint4).
+__global__ __launch_bounds__(256) void k_ws_sort_groups(uint4* __restrict__ stream, int64_t n_chunks) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t c = (int64_t)blockIdx.x * (256 / kWave) + (threadIdx.x / kWave);
+    if (c >= n_chunks) return; // wave-uniform
+    uint4 q = stream[c * kWave + lane];
+    uint32_t v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 2; k <= kWave; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)v[u], j, kWave);
+                v[u] = take_min ? (v[u] < o ? v[u] : o) : (v[u] > o ? v[u] : o);
+            }
+        }
+    }
+    stream[c * kWave + lane] = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 int grid_for(int64_t n, int block) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -371,6 +396,11 @@ hipError_t ws_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     hipLaunchKernelGGL((k_ws_build<true>), dim3(grid_for(n_ws, 64)), dim3(64), 0, s, d_row_ptr, d_col_idx, n_rows,
                        n_events, rw, rw > 4096 ? 14 : 13, n_ws, gcap, d_cnt, (int64_t*)nullptr, (const int64_t*)d_off, d_stream, d_ovf);
     e = hipGetLastError();
+    static const bool no_sort = getenv("CANOPY_WS_NOSORT") != nullptr; // tuning only
+    if (e == hipSuccess && total > 0 && !no_sort) {
+        hipLaunchKernelGGL(k_ws_sort_groups, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, reinterpret_cast<uint4*>(d_stream), total);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return bail(e);
     (void)hipFree(d_cnt);
