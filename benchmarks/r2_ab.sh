@@ -11,8 +11,9 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run ws_sorted X=1 -- --steps 40 --no-also --no-pipeline --kernel 3 --cut-off 0
-run ws_unsorted CANOPY_WS_NOSORT=1 -- --steps 40 --no-also --no-pipeline --kernel 3 --cut-off 0
+run fx_u4 X=1 -- --steps 60 --no-also --cut-off 0 --no-pipeline
+run fx_u6 CANOPY_FX_U=6 -- --steps 60 --no-also --cut-off 0 --no-pipeline
+run fx_u3 CANOPY_FX_U=3 -- --steps 60 --no-also --cut-off 0 --no-pipeline
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):

@@ -28,8 +28,15 @@ def library_comm(ctx, group=None):
     from .quantifier import Comm
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    box = [Comm.unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = Comm.unique_id()
+        except Exception as e:  # noqa: BLE001 -- every rank must learn of it: the others are waiting in the broadcast
+            box[0] = ("error", repr(e))
     dist.broadcast_object_list(box, src=0, group=group)
+    if isinstance(box[0], tuple):
+        raise RuntimeError("canopy_comm_get_unique_id failed on rank 0: %s" % box[0][1])
     return Comm(ctx, box[0], world, rank)
 
 
