@@ -11,9 +11,11 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run fx_u4 X=1 -- --steps 60 --no-also --cut-off 0 --no-pipeline
-run fx_u6 CANOPY_FX_U=6 -- --steps 60 --no-also --cut-off 0 --no-pipeline
-run fx_u3 CANOPY_FX_U=3 -- --steps 60 --no-also --cut-off 0 --no-pipeline
+run base X=1 -- --steps 60 --no-also --no-pipeline
+run noend CANOPY_FR_DEBUG=4 -- --steps 60 --no-also --no-pipeline
+run nohbm_noend CANOPY_FR_DEBUG=5 -- --steps 60 --no-also --no-pipeline
+run nohbm_noend_nobar CANOPY_FR_DEBUG=13 -- --steps 60 --no-also --no-pipeline
+run nohbm_noend_lds2 CANOPY_FR_DEBUG=7 -- --steps 60 --no-also --no-pipeline
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):
