@@ -1491,7 +1491,7 @@ hipError_t launch_fx_sum(const uint32_t* stream, const int64_t* fr_off, int64_t 
             if (allkept) FX2_GO(8, 2, false, true); FX2_GO(8, 2, false, false);
         }
         if (u_env == 2) { if (allkept) FX2_GO(12, 2, false, true); FX2_GO(12, 2, false, false); }
-        if (allkept) FX2_GO(12, 4, false, true); // measured at config 3, cut_off 0: 0.889 ms (U = 2: 0.947, 14 adders: 0.97)
+        if (allkept) FX2_GO(12, 4, false, true); // measured at config 3, cut_off 0: 0.687 ms (U = 2: 0.81, 8 adders: 0.71, 14 adders: 0.94)
         FX2_GO(12, 4, false, false);
 #undef FX2_GO
     }
