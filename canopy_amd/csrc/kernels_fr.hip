@@ -1331,9 +1331,18 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
                                fr_off, total_chunks, q8_buf, P, n_rows, n_slabs, threshold, cand_list, cand_cnt, cand_count, part_max); \
             return hipGetLastError();                                                                                  \
         } while (0)
-        if (u == 2) Q8P_GO(2);
-        if (u == 3) Q8P_GO(3);
-        if (u == 6) Q8P_GO(6);
+        // chunks in flight per wave: a (slab, part) holds total_chunks / (n_slabs * H) chunks on average (97 at E = 2e5); with
+        // U = 4 its loop is one full step of 64 chunks and a second, nearly empty one that costs the same latency; U = 6
+        // covers it in one step (measured at E = 2e5: 0.6245 -> 0.598 ms; U = 8 0.616)
+        static const bool u_forced = getenv("CANOPY_FR_QU") != nullptr;
+        int up = u;
+        if (!u_forced) {
+            const double avg = n_slabs > 0 ? (double)total_chunks / ((double)n_slabs * H) : 0.0;
+            up = (avg * 1.1 > 4.0 * kQ8Waves && avg * 1.1 <= 6.0 * kQ8Waves) ? 6 : 4;
+        }
+        if (up == 2) Q8P_GO(2);
+        if (up == 3) Q8P_GO(3);
+        if (up == 6) Q8P_GO(6);
         Q8P_GO(4);
 #undef Q8P_GO
     }
