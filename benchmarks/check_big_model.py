@@ -18,4 +18,24 @@ w = oracle_py.quantify(rp, col, p, n_threads=cores, want_rows=False)
 print("oracle quantify s", time.time() - t0, int(w.n_kept), int(w.argmax_row), w.rare_event, w.mcub, flush=True)
 ok = got.n_kept == int(w.n_kept) and got.argmax_row == int(w.argmax_row) and got.max_logp == w.max_logp \
      and abs(got.rare_event - w.rare_event) <= 1e-12 * w.rare_event and abs(got.mcub - w.mcub) <= 1e-12 * w.mcub
-print("MATCH" if ok else "MISMATCH")
+print("MATCH" if ok else "MISMATCH", "(cut_off 1e-8, AUTO)", flush=True)
+# the same model with cut_off = 0: every row through exp / log1p (AUTO -> the fixed-point pass + exact refine of the contenders)
+prm0 = canopy_amd.default_params(cut_off=0.0)
+got0 = ctx.quantify(m, prm0)
+for _ in range(3):
+    ctx.quantify_async(m, prm0)
+ctx.synchronize()
+t0 = time.time()
+for _ in range(5):
+    ctx.quantify_async(m, prm0)
+ctx.synchronize()
+dt0 = (time.time() - t0) / 5
+print("gpu cut_off 0:", got0.n_kept, got0.argmax_row, got0.rare_event, got0.mcub, "variant", ctx.last_kernel_variant(), "ms per pass %.3f" % (dt0 * 1e3), flush=True)
+t0 = time.time()
+w0 = oracle_py.quantify(rp, col, p, cut_off=0.0, n_threads=cores, want_rows=False)
+print("oracle quantify (cut_off 0) s", time.time() - t0, int(w0.n_kept), int(w0.argmax_row), w0.rare_event, w0.mcub, flush=True)
+ok0 = got0.n_kept == int(w0.n_kept) and got0.argmax_row == int(w0.argmax_row) and got0.max_logp == w0.max_logp \
+      and abs(got0.rare_event - w0.rare_event) <= 1e-12 * w0.rare_event and abs(got0.mcub - w0.mcub) <= 1e-12 * w0.mcub
+print("MATCH" if ok0 else "MISMATCH", "(cut_off 0)")
+info = m.info()
+print("device_bytes", info.device_bytes, "rows", info.n_rows, "nnz", info.nnz)
