@@ -11,13 +11,10 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run e2e5_auto X=1 -- --no-also --events 200000 --steps 100 --no-pipeline
-run e2e5_u4 CANOPY_FR_QU=4 -- --no-also --events 200000 --steps 100 --no-pipeline
-run e2e5_u6 CANOPY_FR_QU=6 -- --no-also --events 200000 --steps 100 --no-pipeline
-run e2e5_u8 CANOPY_FR_QU=8 -- --no-also --events 200000 --steps 100 --no-pipeline
-run e262k_auto X=1 -- --no-also --events 262144 --steps 100 --no-pipeline
-run e262k_u4 CANOPY_FR_QU=4 -- --no-also --events 262144 --steps 100 --no-pipeline
-run e2e5_pipe X=1 -- --no-also --events 200000 --steps 100
+run p24 CANOPY_FR_VERBOSE=1 -- --steps 60 --no-also --no-pipeline --rows 99999744
+run nop24 CANOPY_FR_NOP24=1 -- --steps 60 --no-also --no-pipeline --rows 99999744
+run p24_pipe CANOPY_FR_VERBOSE=1 -- --steps 100 --no-also --rows 99999744
+run nop24_pipe CANOPY_FR_NOP24=1 -- --steps 100 --no-also --rows 99999744
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):
