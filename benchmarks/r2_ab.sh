@@ -11,10 +11,13 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run p24 CANOPY_FR_VERBOSE=1 -- --steps 60 --no-also --no-pipeline --rows 99999744
-run nop24 CANOPY_FR_NOP24=1 -- --steps 60 --no-also --no-pipeline --rows 99999744
-run p24_pipe CANOPY_FR_VERBOSE=1 -- --steps 100 --no-also --rows 99999744
-run nop24_pipe CANOPY_FR_NOP24=1 -- --steps 100 --no-also --rows 99999744
+run p24 X=1 -- --steps 60 --no-also --no-pipeline
+run nop24 CANOPY_FR_NOP24=1 -- --steps 60 --no-also --no-pipeline
+run p24_pipe X=1 -- --steps 100
+run nop24_pipe CANOPY_FR_NOP24=1 -- --steps 100 --no-also
+run p24_shard8 X=1 -- --steps 200 --no-also --shard-of 8
+run p24_u6 CANOPY_FR_QU=6 -- --steps 60 --no-also --no-pipeline
+run p24_u2 CANOPY_FR_QU=2 -- --steps 60 --no-also --no-pipeline
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):
