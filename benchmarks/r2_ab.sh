@@ -11,13 +11,11 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run p24 X=1 -- --steps 60 --no-also --no-pipeline
-run nop24 CANOPY_FR_NOP24=1 -- --steps 60 --no-also --no-pipeline
-run p24_pipe X=1 -- --steps 100
-run nop24_pipe CANOPY_FR_NOP24=1 -- --steps 100 --no-also
-run p24_shard8 X=1 -- --steps 200 --no-also --shard-of 8
-run p24_u6 CANOPY_FR_QU=6 -- --steps 60 --no-also --no-pipeline
-run p24_u2 CANOPY_FR_QU=2 -- --steps 60 --no-also --no-pipeline
+run rows_lds_n3 X=1 -- --steps 40 --no-also --no-pipeline --events 1000 --kernel 2
+run rows_lds_wide CANOPY_ROWS_WIDE_INDEX=1 -- --steps 40 --no-also --no-pipeline --events 1000 --kernel 2
+run rows_n3 X=1 -- --steps 20 --no-also --no-pipeline --kernel 1
+run rows_wide CANOPY_ROWS_WIDE_INDEX=1 -- --steps 20 --no-also --no-pipeline --kernel 1
+run c2 X=1 -- --no-also --rows 100000 --events 1000 --avg-nnz 4 --steps 1000
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):
