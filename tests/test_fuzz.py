@@ -12,7 +12,7 @@ TOL = 1e-12
 
 
 def random_model(rng):
-    n_events = int(rng.choice([1, 2, 3, 7, 64, 65, 1000, 2049, 5000, 20000]))
+    n_events = int(rng.choice([1, 2, 3, 7, 64, 65, 1000, 2049, 5000, 20000, 120000, 230000]))  # (the last two: the filter's column parts)
     n_rows = int(rng.choice([1, 2, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 16385, 30011]))
     max_len = int(min(n_events, rng.choice([1, 2, 4, 10, 25])))
     lens = rng.integers(0 if rng.random() < 0.3 else 1, max_len + 1, size=n_rows)
