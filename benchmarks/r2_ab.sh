@@ -11,11 +11,9 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run rows_lds_n3 X=1 -- --steps 40 --no-also --no-pipeline --events 1000 --kernel 2
-run rows_lds_wide CANOPY_ROWS_WIDE_INDEX=1 -- --steps 40 --no-also --no-pipeline --events 1000 --kernel 2
-run rows_n3 X=1 -- --steps 20 --no-also --no-pipeline --kernel 1
-run rows_wide CANOPY_ROWS_WIDE_INDEX=1 -- --steps 20 --no-also --no-pipeline --kernel 1
-run c2 X=1 -- --no-also --rows 100000 --events 1000 --avg-nnz 4 --steps 1000
+run shard8_rccl X=1 -- --steps 400 --no-also --shard-of 8 --force-dist
+run shard8 X=1 -- --steps 400 --no-also --shard-of 8
+run shard8_rccl_b X=1 -- --steps 400 --no-also --shard-of 8 --force-dist
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):

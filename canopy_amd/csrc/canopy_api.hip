@@ -761,7 +761,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     ctx->last_set = set;
     hipStream_t last = lane; // the stream the pass ends on
     if (ctx->comm) { // K5: the one collective of the path, issued here (not by the host language), behind the final reduce
-        canopy_status cst = comm_all_reduce_partials(ctx, lane, d_gather, set);
+        canopy_status cst = comm_all_reduce_partials(ctx, lane, d_gather, set, timed);
         if (cst != CANOPY_OK) return cst;
         if (comm_stream(ctx)) last = comm_stream(ctx);
     }

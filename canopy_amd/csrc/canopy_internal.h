@@ -120,6 +120,7 @@ struct canopy_comm {
     hipEvent_t ev_lane[canopy_ctx::kLanes] = {nullptr, nullptr, nullptr}; // "this lane's record is in its slot buffer"
     hipEvent_t ev_fin = nullptr, ev_done = nullptr; // around the last all-reduce (timing)
     bool issued = false;
+    bool timed_valid = false; // ev_fin / ev_done bracket the last collective
     double* last_buf = nullptr; // slot buffer of the last issued collective
     unsigned long long* d_mc = nullptr; // [2] {hits, trials} of the Monte-Carlo combine
     unsigned long long* h_mc = nullptr;
@@ -224,7 +225,7 @@ hipError_t synth_build_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int
 
 // comm_rccl.hip
 // the single collective of a pass, enqueued on the stream its final reduce ran on
-canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane);
+canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane, bool timed);
 hipStream_t comm_stream(canopy_ctx* ctx);
 // orders the context's stream behind everything enqueued on the other lanes (device-side waits, no host blocking)
 hipError_t ctx_join_side(canopy_ctx* ctx);

@@ -116,7 +116,11 @@ canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, ca
     canopy_comm* c = new (std::nothrow) canopy_comm();
     if (!c) return CANOPY_ERR_OUT_OF_MEMORY;
     c->ctx = ctx; c->comm = nc; c->world = world; c->rank = rank;
-    HIPC_TRY(ctx, hipSetDevice(ctx->device));
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        (void)hipGetLastError();
+        delete c;
+        return comm_fail(ctx, CANOPY_ERR_HIP, "hipSetDevice failed");
+    }
     const size_t bytes = sizeof(double) * CANOPY_PARTIAL_DOUBLES * (size_t)world;
     hipError_t e = hipMalloc(&c->d_buf, canopy_ctx::kLanes * bytes);
     if (e == hipSuccess) e = hipHostMalloc(&c->h_buf, bytes);
@@ -152,7 +156,7 @@ namespace canopy {
 
 // Called by canopy_quantify_async right behind k_finalize: buf = the slot buffer of the pass's lane, lane_stream = the
 // stream its final reduce ran on. No host round trip.
-canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane) {
+canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane, bool timed) {
     canopy_comm* c = ctx->comm;
     if (!c || c->deferred) return CANOPY_OK;
     hipStream_t st = lane_stream;
@@ -161,10 +165,13 @@ canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream,
         HIPC_TRY(ctx, hipStreamWaitEvent(c->stream, c->ev_lane[lane], 0));
         st = c->stream;
     }
-    HIPC_TRY(ctx, hipEventRecord(c->ev_fin, st));
+    // the two events around the collective only for a timed pass (an event record is a packet on the stream and a few
+    // microseconds of host time: not on the path of every pass of an 8-way shard)
+    if (timed) HIPC_TRY(ctx, hipEventRecord(c->ev_fin, st));
     RCCL_TRY(ctx, rccl()->AllReduce(buf, buf, (size_t)c->world * CANOPY_PARTIAL_DOUBLES, ncclDouble, ncclSum,
                                     static_cast<ncclComm_t>(c->comm), st));
-    HIPC_TRY(ctx, hipEventRecord(c->ev_done, st));
+    if (timed || c->stream) HIPC_TRY(ctx, hipEventRecord(c->ev_done, st));
+    c->timed_valid = timed;
     c->issued = true;
     c->last_buf = buf;
     return CANOPY_OK;
@@ -330,7 +337,8 @@ canopy_status canopy_comm_fetch(canopy_comm* c, uint32_t flags, canopy_quant_res
 
 canopy_status canopy_comm_last_collective_ms(canopy_comm* c, double* ms) try {
     if (!c || !c->ctx || !ms) return CANOPY_ERR_INVALID_ARGUMENT;
-    if (!c->issued || c->deferred) return comm_fail(c->ctx, CANOPY_ERR_STATE, "no collective to time");
+    if (!c->issued || c->deferred || !c->timed_valid)
+        return comm_fail(c->ctx, CANOPY_ERR_STATE, "no timed collective: the last pass was not timed (canopy_quantify, or a canopy_timing_begin region)");
     HIPC_TRY(c->ctx, hipSetDevice(c->ctx->device));
     HIPC_TRY(c->ctx, hipEventSynchronize(c->ev_done));
     float t = 0.f;

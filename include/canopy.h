@@ -326,7 +326,9 @@ CANOPY_API canopy_status canopy_combine_partials(const canopy_partial* parts, in
 CANOPY_API canopy_status canopy_comm_fetch(canopy_comm* comm, uint32_t flags, canopy_quant_result* result,
                                            canopy_partial* parts);
 
-/* Device time of the last pass's all-reduce (event pair around it on the stream it ran on; waits for it). */
+/* Device time of the last pass's all-reduce (event pair around it on the stream it ran on; waits for it). The pair is
+   recorded for timed passes only -- the synchronous canopy_quantify, or a pass inside canopy_timing_begin/end --
+   CANOPY_ERR_STATE otherwise (an event record costs microseconds a pass of an 8-way shard does not have). */
 CANOPY_API canopy_status canopy_comm_last_collective_ms(canopy_comm* comm, double* ms);
 
 /* Optional per-row outputs of the last pass that requested them (host destination). */
