@@ -67,7 +67,14 @@ def check_against_oracle(ctx, oracle, row_ptr, col, p, n_events, cut_off, limit_
             continue
         prm = default_params(cut_off=cut_off, limit_order=limit_order,
                              flags=_capi.QUANT_ROW_LOGP | _capi.QUANT_KEEP_MASK, kernel=kern)
-        got = ctx.quantify(model, prm)
+        try:
+            got = ctx.quantify(model, prm)
+        except _capi.CanopyError as e:
+            # the explicit-only VALUE_SCATTER layout is placed greedily and may refuse a model (a column every row
+            # contains): CANOPY_ERR_UNSUPPORTED, as canopy.h documents for an explicitly requested variant
+            if kern == _capi.KERNEL_VALUE_SCATTER and e.status == _capi.ERR_UNSUPPORTED:
+                continue
+            raise
         assert got.n_kept == int(want.n_kept), kern
         assert got.argmax_row == int(want.argmax_row), kern
         if want.n_kept:

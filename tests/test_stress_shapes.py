@@ -1,0 +1,78 @@
+"""GPU parity on model shapes chosen to stress the slab-stream builder and the slab passes: a column every row contains,
+all entries of a slab in one column bucket, rows of the longest length the fixed-point pass takes, the last column of
+the widest event space, empty rows between full ones. Every kernel variant against the oracle (tests/test_gpu_parity.py's
+checker: integers and per-row sums bit-exact, rare-event / MCUB within 1e-12)."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import check_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def csr_from_rows(rows):
+    row_ptr = np.zeros(len(rows) + 1, dtype=np.int64)
+    row_ptr[1:] = np.cumsum([len(r) for r in rows])
+    col = np.fromiter((c for r in rows for c in r), dtype=np.int32, count=int(row_ptr[-1]))
+    return row_ptr, col
+
+
+def random_rows(rng, n_rows, lo, hi, max_len, always=()):
+    rows = []
+    for _ in range(n_rows):
+        k = int(rng.integers(0, max_len + 1))
+        extra = rng.choice(np.arange(lo, hi), size=min(k, hi - lo), replace=False) if k else np.empty(0, dtype=np.int64)
+        rows.append(sorted(set(int(c) for c in extra) | set(always)))
+    return rows
+
+
+@pytest.mark.parametrize("cut_off", [0.0, 1e-6])
+def test_a_column_in_every_row(gpu_ctx, oracle, cut_off):
+    rng = np.random.default_rng(11)
+    n_events = 5000
+    rows = random_rows(rng, 20011, 1, n_events, 6, always=(0,))
+    row_ptr, col = csr_from_rows(rows)
+    p = 10.0 ** rng.uniform(-3, -0.5, size=n_events)
+    p[0] = 0.9
+    check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, cut_off, 20)
+
+
+@pytest.mark.parametrize("cut_off", [0.0, 1e-8])
+def test_all_entries_in_one_column_bucket(gpu_ctx, oracle, cut_off):
+    rng = np.random.default_rng(12)
+    n_events = 100_000
+    rows = random_rows(rng, 17000, 500, 600, 5)  # 100 of 1e5 columns: one of the builder's 512 buckets takes everything
+    row_ptr, col = csr_from_rows(rows)
+    p = 10.0 ** rng.uniform(-4, -1, size=n_events)
+    check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, cut_off, 20)
+
+
+@pytest.mark.parametrize("cut_off", [0.0, 1e-30])
+def test_rows_of_63_entries(gpu_ctx, oracle, cut_off):
+    rng = np.random.default_rng(13)
+    n_events = 64
+    rows = [sorted(int(c) for c in rng.choice(n_events, size=63, replace=False)) for _ in range(9000)]
+    rows += [[], [5], list(range(63))]
+    row_ptr, col = csr_from_rows(rows)
+    p = rng.uniform(0.3, 1.0, size=n_events)
+    check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, cut_off, 0)
+
+
+def test_last_column_of_the_widest_event_space(gpu_ctx, oracle):
+    rng = np.random.default_rng(14)
+    n_events = 1 << 18
+    rows = random_rows(rng, 8200, 0, n_events - 1, 4, always=(n_events - 1,))
+    rows[100] = []
+    row_ptr, col = csr_from_rows(rows)
+    p = 10.0 ** rng.uniform(-3, -1, size=n_events)
+    p[n_events - 1] = 0.5
+    check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, 1e-9, 20)
+
+
+def test_empty_rows_between_full_slabs(gpu_ctx, oracle):
+    rng = np.random.default_rng(15)
+    n_events = 3000
+    rows = random_rows(rng, 8192, 0, n_events, 8) + [[] for _ in range(8192)] + random_rows(rng, 700, 0, n_events, 8)
+    row_ptr, col = csr_from_rows(rows)
+    p = 10.0 ** rng.uniform(-2, -0.3, size=n_events)
+    check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, 1e-4, 20)
