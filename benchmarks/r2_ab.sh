@@ -11,14 +11,15 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run p24 X=1 -- --steps 60 --no-also --no-pipeline
-run nop24 CANOPY_FR_NOP24=1 -- --steps 60 --no-also --no-pipeline
-run p24_pipe X=1 -- --steps 100 --no-also
-run nop24_pipe CANOPY_FR_NOP24=1 -- --steps 100 --no-also
-run p24_u2 CANOPY_FR_QU=2 -- --steps 60 --no-also --no-pipeline
-run p24_u3 CANOPY_FR_QU=3 -- --steps 60 --no-also --no-pipeline
-run p24_shard8 X=1 -- --steps 400 --no-also --shard-of 8
-run nop24_shard8 CANOPY_FR_NOP24=1 -- --steps 400 --no-also --shard-of 8
+run co1em11_k0 X=1 -- --steps 40 --no-also --cut-off 1e-11 --kernel 0
+run co1em11_k5 X=1 -- --steps 40 --no-also --cut-off 1e-11 --kernel 5
+run co1em11_k6 X=1 -- --steps 40 --no-also --cut-off 1e-11 --kernel 6
+run co1em12_k0 X=1 -- --steps 40 --no-also --cut-off 1e-12 --kernel 0
+run co1em12_k5 X=1 -- --steps 40 --no-also --cut-off 1e-12 --kernel 5
+run co1em12_k6 X=1 -- --steps 40 --no-also --cut-off 1e-12 --kernel 6
+run co1em13_k0 X=1 -- --steps 40 --no-also --cut-off 1e-13 --kernel 0
+run co1em13_k5 X=1 -- --steps 40 --no-also --cut-off 1e-13 --kernel 5
+run co1em13_k6 X=1 -- --steps 40 --no-also --cut-off 1e-13 --kernel 6
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):

@@ -512,13 +512,22 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     int variant = params->kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : params->kernel;
     // AUTO: with a positive cut-off and no per-row output, filter/refine replaces the row kernels once the
     // model is large enough to amortise its four launches (measured crossovers: ~8e6 rows against the
-    // LDS-table row kernel, ~1e6 rows against the wave-slab stream), unless its filter flagged > 20 % of
-    // the rows last time.
+    // LDS-table row kernel, ~1e6 rows against the wave-slab stream), unless its filter listed too many of
+    // the rows last time (fr_leave_at).
+    // Where filter/refine stops paying depends on what takes over: against the fixed-point pass (0.69 ms per 1e8 rows
+    // whatever the survivors) the crossover is at ~10 % of the rows listed (measured at config 3, pipelined steps, cut-offs
+    // 1e-9 .. 1e-13: 0.43 ms at 2 % survivors, 0.55 at 5.7 %, 0.68 at 8 %, 0.69 at 10 %), against the exact CSR-order
+    // stream kernel (1.2-1.5 ms) at ~20 %.
+    const bool fx_can_take_over = variant == CANOPY_KERNEL_WAVE_STREAM && m->n_events >= 1 && m->n_events <= fr_max_events() &&
+                                  m->n_rows >= (int64_t)1000000 && m->max_row_len <= fx_max_row_len() &&
+                                  !(ctx->fx_known_id == m->id && ctx->fx_known_fraction > 0.2 &&
+                                    ctx->fx_known_cut_off == params->cut_off && ctx->fx_known_version == m->logp_version);
+    const double fr_leave_at = fx_can_take_over ? 0.10 : 0.2;
     if (params->kernel == CANOPY_KERNEL_AUTO && params->cut_off > 0.0 && !want_rows_early &&
         m->n_events >= 1 && m->n_events <= fr_max_events() &&
         m->n_rows >= (variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)8000000 : (int64_t)1000000) &&
         (variant == CANOPY_KERNEL_WAVE_STREAM || variant == CANOPY_KERNEL_ROWS_LDS) &&
-        !(ctx->fr_known_id == m->id && ctx->fr_known_fraction > 0.2 && ctx->fr_known_cut_off == params->cut_off &&
+        !(ctx->fr_known_id == m->id && ctx->fr_known_fraction > fr_leave_at && ctx->fr_known_cut_off == params->cut_off &&
           ctx->fr_known_version == m->logp_version)) {
         canopy_status pst = build_fr(ctx, const_cast<canopy_model*>(m));
         if (pst != CANOPY_OK) return pst;
