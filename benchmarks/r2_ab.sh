@@ -11,15 +11,10 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run co1em11_k0 X=1 -- --steps 40 --no-also --cut-off 1e-11 --kernel 0
-run co1em11_k5 X=1 -- --steps 40 --no-also --cut-off 1e-11 --kernel 5
-run co1em11_k6 X=1 -- --steps 40 --no-also --cut-off 1e-11 --kernel 6
-run co1em12_k0 X=1 -- --steps 40 --no-also --cut-off 1e-12 --kernel 0
-run co1em12_k5 X=1 -- --steps 40 --no-also --cut-off 1e-12 --kernel 5
-run co1em12_k6 X=1 -- --steps 40 --no-also --cut-off 1e-12 --kernel 6
-run co1em13_k0 X=1 -- --steps 40 --no-also --cut-off 1e-13 --kernel 0
-run co1em13_k5 X=1 -- --steps 40 --no-also --cut-off 1e-13 --kernel 5
-run co1em13_k6 X=1 -- --steps 40 --no-also --cut-off 1e-13 --kernel 6
+run main X=1 -- --steps 60 --no-also
+run e1k_k0 X=1 -- --steps 40 --no-also --cut-off 0 --events 1000 --kernel 0
+run e1k_k0_co X=1 -- --steps 40 --no-also --events 1000 --kernel 0
+run c2 X=1 -- --no-also --rows 100000 --events 1000 --avg-nnz 4 --steps 1000
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):

@@ -518,8 +518,10 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     // whatever the survivors) the crossover is at ~10 % of the rows listed (measured at config 3, pipelined steps, cut-offs
     // 1e-9 .. 1e-13: 0.43 ms at 2 % survivors, 0.55 at 5.7 %, 0.68 at 8 %, 0.69 at 10 %), against the exact CSR-order
     // stream kernel (1.2-1.5 ms) at ~20 %.
-    const bool fx_can_take_over = variant == CANOPY_KERNEL_WAVE_STREAM && m->n_events >= 1 && m->n_events <= fr_max_events() &&
-                                  m->n_rows >= (int64_t)1000000 && m->max_row_len <= fx_max_row_len() &&
+    const bool fx_can_take_over = (variant == CANOPY_KERNEL_WAVE_STREAM || variant == CANOPY_KERNEL_ROWS_LDS) &&
+                                  m->n_events >= 1 && m->n_events <= fr_max_events() &&
+                                  m->n_rows >= (variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)8000000 : (int64_t)1000000) &&
+                                  m->max_row_len <= fx_max_row_len() &&
                                   !(ctx->fx_known_id == m->id && ctx->fx_known_fraction > 0.2 &&
                                     ctx->fx_known_cut_off == params->cut_off && ctx->fx_known_version == m->logp_version);
     const double fr_leave_at = fx_can_take_over ? 0.10 : 0.2;
@@ -536,10 +538,9 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     // AUTO, sum-only pass that filter/refine does not serve (cut_off = 0, or a cut-off most rows survive): the
     // order-independent fixed-point pass instead of the exact CSR-order stream kernel, unless IT had to hand > 20 % of
     // the rows to the exact pass last time (huge |s|, clamped entries)
-    if (params->kernel == CANOPY_KERNEL_AUTO && variant == CANOPY_KERNEL_WAVE_STREAM && !want_rows_early &&
-        m->n_events >= 1 && m->n_events <= fr_max_events() && m->n_rows >= (int64_t)1000000 && m->max_row_len <= fx_max_row_len() &&
-        !(ctx->fx_known_id == m->id && ctx->fx_known_fraction > 0.2 && ctx->fx_known_cut_off == params->cut_off &&
-          ctx->fx_known_version == m->logp_version)) {
+    // (also for E <= 2048 at scale, where the row kernel with the table in LDS would run: 1e8 rows, E = 1e3, cut_off 0:
+    // 1.01 ms against 0.54 with the fixed-point table in LDS; 1e7 rows: 0.117 against 0.088)
+    if (params->kernel == CANOPY_KERNEL_AUTO && !want_rows_early && fx_can_take_over && variant != CANOPY_KERNEL_FILTER_REFINE) {
         canopy_status pst = build_fr(ctx, const_cast<canopy_model*>(m));
         if (pst != CANOPY_OK) return pst;
         if (m->fr_state == 1) variant = CANOPY_KERNEL_FIXED_SUM;
