@@ -419,9 +419,17 @@ int auto_variant(const canopy_model* m) {
     // measured on MI355X (avg 6 nnz/row, 1e8 rows): the LDS-table row kernel wins up to E = 2048 (two
     // workgroups per CU still fit); beyond that the table costs occupancy and the wave-slab stream wins
     if (m->n_events <= 2048) return CANOPY_KERNEL_ROWS_LDS;
-    if (m->n_events <= ws_max_events()) return CANOPY_KERNEL_WAVE_STREAM;
+    // round 2, E = 1e5, every row kept: ROWS 64 us / 113 us at 2e6 / 4e6 rows, WAVE_STREAM 72 / 75 (a ~50 us floor: few
+    // wave-slabs, one wave each): the stream kernel from 2.5e6 rows
+    if (m->n_events <= ws_max_events() && m->n_rows >= (int64_t)2500000) return CANOPY_KERNEL_WAVE_STREAM;
     return CANOPY_KERNEL_ROWS;
 }
+
+// Sizes from which the two slab passes replace the row kernel AUTO would run (round 2, pipelined and serial passes at
+// E = 1e3 and 1e5: filter/refine is level with the row kernels at ~4e5 .. 7e5 rows serially and ahead from 1e5 rows in a
+// pipelined sequence; the fixed-point pass is level with ROWS_LDS at ~3e6 rows, with ROWS / WAVE_STREAM at ~1e6)
+int64_t fr_min_rows(int base_variant) { return base_variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)1000000 : (int64_t)500000; }
+int64_t fx_min_rows(int base_variant) { return base_variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)4000000 : (int64_t)1000000; }
 
 canopy_status build_fr(canopy_ctx* ctx, canopy_model* m) {
     if (m->fr_state != 0) return CANOPY_OK;
@@ -463,8 +471,7 @@ extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, 
     if (m->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "model lives on another device");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int variant = kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : kernel;
-    if (kernel == CANOPY_KERNEL_AUTO && m->n_events >= 1 && m->n_events <= fr_max_events() &&
-        m->n_rows >= (variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)8000000 : (int64_t)1000000)) {
+    if (kernel == CANOPY_KERNEL_AUTO && m->n_events >= 1 && m->n_events <= fr_max_events() && m->n_rows >= fr_min_rows(variant)) {
         canopy_status fst = build_fr(ctx, m); // AUTO picks filter/refine for cut_off > 0
         if (fst != CANOPY_OK) return fst;
         // the stream of the exact all-rows kernel (cut_off = 0, per-row output, > 20 % survivors) is built by the
@@ -511,24 +518,19 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
     const bool want_rows_early = (params->flags & CANOPY_QUANT_ROW_LOGP) != 0;
     int variant = params->kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : params->kernel;
     // AUTO: with a positive cut-off and no per-row output, filter/refine replaces the row kernels once the
-    // model is large enough to amortise its four launches (measured crossovers: ~8e6 rows against the
-    // LDS-table row kernel, ~1e6 rows against the wave-slab stream), unless its filter listed too many of
+    // model is large enough to amortise its launches (fr_min_rows), unless its filter listed too many of
     // the rows last time (fr_leave_at).
     // Where filter/refine stops paying depends on what takes over: against the fixed-point pass (0.69 ms per 1e8 rows
     // whatever the survivors) the crossover is at ~10 % of the rows listed (measured at config 3, pipelined steps, cut-offs
     // 1e-9 .. 1e-13: 0.43 ms at 2 % survivors, 0.55 at 5.7 %, 0.68 at 8 %, 0.69 at 10 %), against the exact CSR-order
     // stream kernel (1.2-1.5 ms) at ~20 %.
-    const bool fx_can_take_over = (variant == CANOPY_KERNEL_WAVE_STREAM || variant == CANOPY_KERNEL_ROWS_LDS) &&
-                                  m->n_events >= 1 && m->n_events <= fr_max_events() &&
-                                  m->n_rows >= (variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)8000000 : (int64_t)1000000) &&
+    const bool fx_can_take_over = m->n_events >= 1 && m->n_events <= fr_max_events() && m->n_rows >= fx_min_rows(variant) &&
                                   m->max_row_len <= fx_max_row_len() &&
                                   !(ctx->fx_known_id == m->id && ctx->fx_known_fraction > 0.2 &&
                                     ctx->fx_known_cut_off == params->cut_off && ctx->fx_known_version == m->logp_version);
     const double fr_leave_at = fx_can_take_over ? 0.10 : 0.2;
     if (params->kernel == CANOPY_KERNEL_AUTO && params->cut_off > 0.0 && !want_rows_early &&
-        m->n_events >= 1 && m->n_events <= fr_max_events() &&
-        m->n_rows >= (variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)8000000 : (int64_t)1000000) &&
-        (variant == CANOPY_KERNEL_WAVE_STREAM || variant == CANOPY_KERNEL_ROWS_LDS) &&
+        m->n_events >= 1 && m->n_events <= fr_max_events() && m->n_rows >= fr_min_rows(variant) &&
         !(ctx->fr_known_id == m->id && ctx->fr_known_fraction > fr_leave_at && ctx->fr_known_cut_off == params->cut_off &&
           ctx->fr_known_version == m->logp_version)) {
         canopy_status pst = build_fr(ctx, const_cast<canopy_model*>(m));
