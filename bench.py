@@ -278,7 +278,7 @@ def main():
     variant = ctx.last_kernel_variant()  # what AUTO resolved to, reported by the library
     kernel_label = KERNEL_LABELS.get(variant, "?")
     if variant == 5 and info.n_events > 112 * 1024:
-        kernel_label = "k_fr_filter + k_fr_refine (gathered fp64 filter, then exact refine)"
+        kernel_label = "k_fr_filter_q8p + k_fr_refine (quantised filter, one column part of the table resident per sweep; then exact refine)"
 
     info = model.info()  # (before the all-rows leg adds its own layout to device_bytes)
 

@@ -11,16 +11,12 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run a_2e5 X=1 -- --steps 400 --no-also --rows 200000
-run a_6e5 X=1 -- --steps 400 --no-also --rows 600000
-run a_1e6_c0 X=1 -- --steps 300 --no-also --rows 1200000 --cut-off 0
-run a_8e5_c0 X=1 -- --steps 300 --no-also --rows 800000 --cut-off 0
-run a_3e6_c0 X=1 -- --steps 300 --no-also --rows 3000000 --cut-off 0
-run a_e1k_3e6_c0 X=1 -- --steps 300 --no-also --rows 3000000 --cut-off 0 --events 1000
-run a_e1k_5e6_c0 X=1 -- --steps 300 --no-also --rows 5000000 --cut-off 0 --events 1000
-run a_e1k_2e6 X=1 -- --steps 300 --no-also --rows 2000000 --events 1000
-run a_main X=1 -- --steps 60 --no-also
-run a_c2 X=1 -- --no-also --rows 100000 --events 1000 --avg-nnz 4 --steps 1000
+run p24_0 X=1 -- --steps 200 --no-also
+run nop24_0 CANOPY_FR_NOP24=1 -- --steps 200 --no-also
+run p24_1 X=1 -- --steps 200 --no-also
+run nop24_1 CANOPY_FR_NOP24=1 -- --steps 200 --no-also
+run p24_2 X=1 -- --steps 200 --no-also
+run nop24_2 CANOPY_FR_NOP24=1 -- --steps 200 --no-also
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):

@@ -77,6 +77,10 @@ void free_model_buffers(canopy_model* m) {
     if (m->d_fr_stream) (void)hipFree(m->d_fr_stream);
     if (m->d_fr_off) (void)hipFree(m->d_fr_off);
     m->d_fr_stream = nullptr; m->d_fr_off = nullptr; m->fr_state = 0;
+    if (m->fr24.stream) (void)hipFree(m->fr24.stream);
+    if (m->fr24.base) (void)hipFree(m->fr24.base);
+    if (m->fr24.exc) (void)hipFree(m->fr24.exc);
+    m->fr24 = FrP24Owned();
     m->d_vs_stream = nullptr; m->d_vs_off = nullptr; m->d_vs_slab_row = nullptr; m->vs_state = 0;
     m->d_row_ptr = nullptr; m->d_col_idx = nullptr; m->d_logp = nullptr;
     m->d_ws_stream = nullptr; m->d_ws_off = nullptr; m->ws_state = 0;
@@ -373,9 +377,9 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
     info->n_events = m->n_events; info->max_row_len = m->max_row_len;
     info->device_bytes = m->device_bytes;
     info->stream_bytes = 0;
-    if (m->fr_state == 1)
-        info->stream_bytes = m->fr_total_chunks * 1024 + (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8 + m->n_fr_slabs * 8 +
-                             (int64_t)m->n_events * 8;
+    if (m->fr_state == 1) // what the quantised filter streams: the 24-bit form when the model has one
+        info->stream_bytes = m->fr_total_chunks * (m->fr24.stream ? 768 + 4 : 1024) + (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8 +
+                             m->n_fr_slabs * 8 + (int64_t)m->n_events * 8;
     else if (m->vs_state == 1)
         info->stream_bytes = m->vs_total_chunks * 1024 + (m->n_slabs + 1) * 16 + (m->n_rows + 1) * 8 + (int64_t)m->n_events * 8;
     else if (m->ws_state == 1)
@@ -439,7 +443,28 @@ canopy_status build_fr(canopy_ctx* ctx, canopy_model* m) {
     HIP_TRY(ctx, fr_build_sorted32(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, m->d_fr_off, m->fr_total_chunks,
                                    m->n_fr_slabs, &m->d_fr_stream, ctx->stream));
     m->device_bytes += (m->fr_total_chunks + 1) * 1024 + (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8;
+    HIP_TRY(ctx, fr_build_pack24(m->d_fr_stream, m->d_fr_off, m->n_fr_slabs, m->fr_total_chunks, m->n_events, &m->fr24, ctx->stream));
+    if (m->fr24.stream) {
+        m->device_bytes += (m->fr_total_chunks + 1) * (768 + 4) + (m->n_fr_slabs + 1) * 4;
+        // the quantised filter reads the 24-bit form only: the 32-bit stream goes, and comes back (ensure_fr32, ~15 ms at
+        // 1e8 rows) for the first pass that reads it -- the fixed-point pass, the gathered fp64 filter
+        static const bool keep32 = getenv("CANOPY_FR_KEEP32") != nullptr; // tuning only
+        if (!keep32) {
+            (void)hipFree(m->d_fr_stream);
+            m->d_fr_stream = nullptr;
+            m->device_bytes -= (m->fr_total_chunks + 1) * 1024;
+        }
+    }
     m->fr_state = 1;
+    return CANOPY_OK;
+}
+
+// the 32-bit slab stream of a model whose build_fr gave it up for the 24-bit form
+canopy_status ensure_fr32(canopy_ctx* ctx, canopy_model* m) {
+    if (m->fr_state != 1 || m->d_fr_stream != nullptr) return CANOPY_OK;
+    HIP_TRY(ctx, fr_build_sorted32(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, m->d_fr_off, m->fr_total_chunks,
+                                   m->n_fr_slabs, &m->d_fr_stream, ctx->stream));
+    m->device_bytes += (m->fr_total_chunks + 1) * 1024;
     return CANOPY_OK;
 }
 
@@ -485,6 +510,7 @@ extern "C" canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, 
         if (m->fr_state != 1) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a filter/refine stream");
         if (variant == CANOPY_KERNEL_FIXED_SUM && m->max_row_len > fx_max_row_len())
             return fail(ctx, CANOPY_ERR_UNSUPPORTED, "FIXED_SUM needs rows of at most 63 entries");
+        if (variant == CANOPY_KERNEL_FIXED_SUM) return ensure_fr32(ctx, m); // (the filter reads the 24-bit form when there is one)
         return CANOPY_OK;
     }
     if (variant == CANOPY_KERNEL_VALUE_SCATTER) {
@@ -557,6 +583,15 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         canopy_status pst = build_fr(ctx, const_cast<canopy_model*>(m));
         if (pst != CANOPY_OK) return pst;
         if (m->fr_state != 1) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a filter/refine stream");
+        // the 32-bit form of the stream, if this pass reads it and the model gave it up for the 24-bit one
+        const bool reads_p24 = variant == CANOPY_KERNEL_FILTER_REFINE && fr_filter_is_quantised(m->n_events) && m->fr24.stream != nullptr;
+        if (!reads_p24 && m->d_fr_stream == nullptr) {
+            if (ctx->capturing) return fail(ctx, CANOPY_ERR_STATE, "the slab stream must exist before a capture");
+            pst = join_side(ctx);
+            if (pst != CANOPY_OK) return pst;
+            pst = ensure_fr32(ctx, const_cast<canopy_model*>(m));
+            if (pst != CANOPY_OK) return pst;
+        }
     }
     if (variant != CANOPY_KERNEL_ROWS && variant != CANOPY_KERNEL_ROWS_LDS && variant != CANOPY_KERNEL_WAVE_STREAM &&
         variant != CANOPY_KERNEL_VALUE_SCATTER && variant != CANOPY_KERNEL_FILTER_REFINE && variant != CANOPY_KERNEL_FIXED_SUM)
@@ -727,7 +762,9 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
                 if (st != CANOPY_OK) return st;
                 if (lane != ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             }
-            HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, mm->d_q8, m->n_rows,
+            FrP24 p24;
+            p24.stream = m->fr24.stream; p24.base = m->fr24.base; p24.exc = m->fr24.exc;
+            HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, &p24, m->d_fr_off, m->fr_total_chunks, m->d_logp, mm->d_q8, m->n_rows,
                                              m->n_events, m->n_fr_slabs, a.log_cut, S.d_fr_list, S.d_fr_cnt, S.d_fr_count,
                                              ctx->n_cu, table_valid, lane));
             if (!table_valid && !ctx->capturing) HIP_TRY(ctx, hipStreamSynchronize(lane));

@@ -149,6 +149,13 @@ struct canopy_dag {
     bool has_p = false;
 };
 
+struct FrP24Owned { // device buffers of the 24-bit stream form, owned by the model
+    uint32_t* stream = nullptr;
+    uint32_t* base = nullptr;
+    int32_t* exc = nullptr;
+    int64_t n_exception_slabs = 0;
+};
+
 struct canopy_model {
     uint64_t id = 0; // unique per process (never reused): contexts refer to models by id, not by pointer
     int device = 0;
@@ -180,6 +187,7 @@ struct canopy_model {
     uint32_t* d_fr_stream = nullptr;
     int64_t* d_fr_off = nullptr;
     int64_t fr_total_chunks = 0, n_fr_slabs = 0;
+    FrP24Owned fr24; // 24-bit form of the same chunks (quantised filter), or nulls
     int fr_state = 0;
 };
 
@@ -268,10 +276,19 @@ hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64
                             int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint16_t* cand_list,
                             unsigned* cand_cnt, unsigned long long* cand_count, int n_cu, hipStream_t s);
 bool fr_filter_is_quantised(int32_t n_events);
-hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
-                               uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs, double log_cut,
-                               uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count, int n_cu,
-                               bool table_valid, hipStream_t s);
+// the 24-bit form of the slab stream (kernels_fr.hip, "P24"): what the quantised filter reads when the model allows it
+struct FrP24 {
+    const uint32_t* stream = nullptr; // 768-byte chunks at the 32-bit stream's chunk indices
+    const uint32_t* base = nullptr;   // first column of every chunk
+    const int32_t* exc = nullptr;     // [n_slabs] 1 = exception slab (all rows go to the exact pass)
+};
+bool fr_p24_applies(int32_t n_events);
+hipError_t fr_build_pack24(const uint32_t* d_stream32, const int64_t* d_fr_off, int64_t n_slabs, int64_t total_chunks, int32_t n_events,
+                           FrP24Owned* p, hipStream_t s);
+hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, const int64_t* fr_off, int64_t total_chunks,
+                               const double* logp, uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs,
+                               double log_cut, uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count,
+                               int n_cu, bool table_valid, hipStream_t s);
 // flagged: the lists come from launch_fx_sum (flag bits 15 / 14 per entry); records go to block_partials[part_offset + block]
 hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, const unsigned* cand_cnt, int slab_rows,
                             int64_t n_slabs, uint64_t* keep_mask, int grid, bool flagged, int part_offset, hipStream_t s);

@@ -255,6 +255,58 @@ __global__ __launch_bounds__(256) void k_fr_fill(uint32_t* p, int64_t n, uint32_
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v + (uint32_t)((i >> 2) & 63);
 }
 
+// ---- the 24-bit form of the slab stream ("P24": what the quantised filter streams when the model allows) --------
+// The same chunks at the same chunk indices, three bytes per entry: (col - first column of the chunk) << 14 | row_local.
+// A chunk of 256 column-sorted entries spans ~520 columns at config 3; a slab with a chunk that spans 1024 columns or more
+// (a sparse slab: the last, partial one of a model) is an EXCEPTION slab: the filter reads nothing of it and hands all its
+// rows to the exact pass (<= 8192 rows). More than 1 % of such slabs: the model keeps the 32-bit form only. Lane k's 12
+// bytes hold its four entries (sorted positions k, 64 + k, ...), one u32 per chunk holds the chunk's first column.
+// 18.1 B per cut set instead of 24.1 at no extra LDS work and ~1.5 more vector instructions per 64 entries. Measured:
+// 1.25e7-row shard (the 8-GPU case) 54.7 -> 49.6 us per pipelined step; whole 1e8-row model 0.440 -> 0.422 ms per serial
+// pass and no change pipelined (0.374: there the pass is level with its own instruction stream).
+constexpr uint32_t kP24ColSpan = 1u << 10;
+
+__global__ __launch_bounds__(256) void k_fr_pack24(const uint4* __restrict__ stream32, const int64_t* __restrict__ fr_off,
+                                                   int64_t n_slabs, int64_t total_chunks, int row_bits, int slab_rows,
+                                                   uint32_t* __restrict__ out24, uint32_t* __restrict__ base,
+                                                   int32_t* __restrict__ exc, int* __restrict__ n_exc) {
+    __shared__ int s_bad;
+    const int64_t s = blockIdx.x; // slab n_slabs = the no-op chunk
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int64_t c0 = s < n_slabs ? fr_off[s] : total_chunks, c1 = s < n_slabs ? fr_off[s + 1] : total_chunks + 1;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    const uint32_t row_mask = (1u << row_bits) - 1u;
+    bool bad = false;
+    for (int64_t c = c0 + wave; c < c1; c += 4) {
+        const uint4 q = stream32[c * kWave + lane];
+        const uint32_t e[4] = {q.x, q.y, q.z, q.w};
+        // sorted position 0 = lane 0's first entry; a padding entry there means the chunk is all padding
+        const uint32_t first = __builtin_amdgcn_readfirstlane(q.x);
+        const uint32_t col0 = (first & row_mask) >= (uint32_t)slab_rows ? 0u : (first >> row_bits);
+        uint32_t pk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t rl = e[k] & row_mask, col = e[k] >> row_bits;
+            const bool pad = rl >= (uint32_t)slab_rows;
+            const uint32_t off = pad ? 0u : col - col0; // ascending columns: col >= col0
+            bad = bad || off >= kP24ColSpan;
+            pk[k] = ((off & (kP24ColSpan - 1u)) << 14) | rl;
+        }
+        uint32_t* o = out24 + (c * kWave + lane) * 3;
+        o[0] = pk[0] | (pk[1] << 24);
+        o[1] = (pk[1] >> 8) | (pk[2] << 16);
+        o[2] = (pk[2] >> 16) | (pk[3] << 8);
+        if (lane == 0) base[c] = col0;
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && s < n_slabs) {
+        exc[s] = s_bad;
+        if (s_bad) atomicAdd(n_exc, 1);
+    }
+}
+
 __device__ __forceinline__ int64_t fr_uload(const int64_t* __restrict__ p) {
     const int64_t v = *p;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
@@ -416,8 +468,51 @@ constexpr int kQ8SlabRows = 8192, kQ8RowBits = 14, kQ8Waves = 16, kQ8Threads = k
 constexpr uint32_t kQ8RowMask = (1u << kQ8RowBits) - 1;
 constexpr size_t kQ8SumsBytes = (size_t)(kQ8SlabRows + 64) * 4;
 
-template <int U>
-__global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __restrict__ stream,
+struct Q8Chunk { // one lane's share of a chunk in flight: 32-bit form x y z w = four entries; 24-bit form x y z = 12 packed bytes, w = the chunk's first column
+    uint32_t x, y, z, w;
+};
+
+template <bool P24>
+__device__ __forceinline__ Q8Chunk q8_load_chunk(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ cbase, int64_t c, int lane) {
+    Q8Chunk r;
+    if (P24) {
+        const uint32_t* p = stream + (c * kWave + lane) * 3;
+        r.x = p[0]; r.y = p[1]; r.z = p[2];
+        // The chunk's first column: a VECTOR load (all lanes the same address). Left to the compiler this wave-uniform load
+        // becomes s_load_dword, whose completion shares lgkmcnt with the LDS operations and returns out of order: every
+        // step then waits (lgkmcnt(0)) for the NEXT step's scalar loads -- a full memory latency -- before its first LDS
+        // add. (That is what held the first 24-bit and 16-bit attempts at the 32-bit stream's time.)
+        // (address space 1 = global: a generic pointer would become flat_load, which counts in lgkmcnt as well)
+        typedef const uint32_t __attribute__((address_space(1))) * global_u32_ptr;
+        uint64_t a = (uint64_t)(cbase + c);
+        asm volatile("" : "+v"(a));
+        r.w = *(global_u32_ptr)a;
+    } else {
+        const uint4 v = reinterpret_cast<const uint4*>(stream)[c * kWave + lane];
+        r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    }
+    return r;
+}
+
+// column and row slot of a chunk's four entries
+template <bool P24>
+__device__ __forceinline__ void q8_decode(const Q8Chunk& q, uint32_t (&col)[4], uint32_t (&row)[4]) {
+    if (P24) {
+        const uint32_t e0 = q.x, e1 = __builtin_amdgcn_alignbit(q.y, q.x, 24), e2 = __builtin_amdgcn_alignbit(q.z, q.y, 16), e3 = q.z >> 8;
+        col[0] = q.w + ((e0 >> 14) & (kP24ColSpan - 1u)); row[0] = e0 & kQ8RowMask;
+        col[1] = q.w + ((e1 >> 14) & (kP24ColSpan - 1u)); row[1] = e1 & kQ8RowMask;
+        col[2] = q.w + ((e2 >> 14) & (kP24ColSpan - 1u)); row[2] = e2 & kQ8RowMask;
+        col[3] = q.w + (e3 >> 14);                         row[3] = e3 & kQ8RowMask;
+    } else {
+        const uint32_t e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { col[k] = e[k] >> kQ8RowBits; row[k] = e[k] & kQ8RowMask; }
+    }
+}
+
+template <int U, bool P24>
+__global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ cbase,
+                                                             const int32_t* __restrict__ exc,
                                                              const int64_t* __restrict__ fr_off, int64_t total_chunks,
                                                              const uint8_t* __restrict__ q8, int32_t n_events,
                                                              int64_t n_rows, int64_t n_slabs, int threshold,
@@ -433,13 +528,13 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
     const int64_t G = (int64_t)gridDim.x;
     // the first chunks of a slab are requested BEFORE the workgroup-wide steps in front of it (table staging here,
     // the previous slab's end step in the loop): no slab starts with a cold stream
-    uint4 q[U];
+    Q8Chunk q[U];
 #define FR_FIRST_CHUNKS(SLAB)                                                                       \
     if ((SLAB) < n_slabs) {                                                                         \
         const int64_t f0 = fr_uload(fr_off + (SLAB)), f1 = fr_uload(fr_off + (SLAB) + 1);           \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                             \
             const int64_t c = f0 + wave + (int64_t)u * kQ8Waves;                                    \
-            q[u] = stream[(c < f1 ? c : total_chunks) * kWave + lane];                              \
+            q[u] = q8_load_chunk<P24>(stream, cbase, c < f1 ? c : total_chunks, lane);              \
         }                                                                                           \
     }
     FR_FIRST_CHUNKS((int64_t)blockIdx.x)
@@ -453,34 +548,39 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
 
     unsigned long long n_cand = 0;
     for (int64_t s = (int64_t)blockIdx.x; s < n_slabs; s += G) {
-        const int64_t c0 = fr_uload(fr_off + s), c1 = fr_uload(fr_off + s + 1);
+        const int64_t c0 = fr_uload(fr_off + s);
+        // an exception slab of the 24-bit form (a chunk too wide for the 10-bit column offset): no chunk is read, every row
+        // goes to the exact pass
+        const bool all_rows = P24 && __builtin_amdgcn_readfirstlane(exc[s]) != 0;
+        const int64_t c1 = all_rows ? c0 : fr_uload(fr_off + s + 1);
         if (abl & 16) { FR_FIRST_CHUNKS(s) } // A/B switch (CANOPY_FR_DEBUG=16): the slab's first chunks requested only now
         for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * kQ8Waves) {
-            uint4 qn[U]; // next step's chunks first: nothing else is in the vector-memory queue
+            Q8Chunk qn[U]; // next step's chunks first: nothing else is in the vector-memory queue
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t c = cb + (int64_t)(U + u) * kQ8Waves;
                 // timing ablation (CANOPY_FR_DEBUG=1, wrong results): every slab re-reads its first 64 chunks, which
                 // stay cache-resident -> the pass without its HBM stream
                 const int64_t cc = (abl & 1) ? c0 + ((c - c0) & 63) : c;
-                qn[u] = stream[(c < c1 ? cc : total_chunks) * kWave + lane];
+                qn[u] = q8_load_chunk<P24>(stream, cbase, c < c1 ? cc : total_chunks, lane);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint32_t e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                uint32_t col[4], row[4];
+                q8_decode<P24>(q[u], col, row);
                 unsigned v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = tab[e[k] >> kQ8RowBits];
+                for (int k = 0; k < 4; ++k) v[k] = tab[col[k]];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    __hip_atomic_fetch_add(&sums[e[k] & kQ8RowMask], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&sums[row[k]], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (abl & 2) { // timing ablation (CANOPY_FR_DEBUG=2, wrong results): the LDS work of every chunk twice
                     unsigned v2[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v2[k] = tab[(e[k] >> kQ8RowBits) ^ 1u];
+                    for (int k = 0; k < 4; ++k) v2[k] = tab[col[k] ^ 1u];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        __hip_atomic_fetch_add(&sums[(e[k] & kQ8RowMask) ^ 1u], v2[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&sums[row[k] ^ 1u], v2[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
 #pragma unroll
@@ -498,7 +598,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint4* __rest
             const int rl = i * kQ8Threads + tid;
             const int sv = (int)sums[rl];
             sums[rl] = 0u;
-            m[i] = __ballot(r0 + rl < n_rows && sv <= threshold);
+            m[i] = __ballot(r0 + rl < n_rows && (all_rows || sv <= threshold));
         }
         if (lane == 0) {
 #pragma unroll
@@ -1189,6 +1289,46 @@ __global__ __launch_bounds__(kFx2Waves * kWave) void k_fx2(const uint4* __restri
 
 } // namespace
 
+// The 24-bit form of an existing 32-bit slab stream (one column part, 8192-row slabs). p->stream stays null (nothing
+// allocated) when more than 1 % of the slabs are exception slabs: the model then keeps the 32-bit form.
+bool fr_p24_applies(int32_t n_events) {
+    static const bool off = getenv("CANOPY_FR_NOP24") != nullptr; // tuning only
+    return !off && fr_use_q8(n_events) && fr_parts_for(n_events) == 1 && fr_slab_rows_for(n_events) == kQ8SlabRows;
+}
+
+hipError_t fr_build_pack24(const uint32_t* d_stream32, const int64_t* d_fr_off, int64_t n_slabs, int64_t total_chunks, int32_t n_events,
+                           FrP24Owned* p, hipStream_t s) {
+    p->stream = nullptr; p->base = nullptr; p->exc = nullptr; p->n_exception_slabs = 0;
+    if (!fr_p24_applies(n_events) || n_slabs <= 0) return hipSuccess;
+    const int64_t n = total_chunks + 1; // + the no-op chunk
+    uint32_t* out = nullptr;
+    uint32_t* base = nullptr;
+    int32_t* exc = nullptr;
+    int* d_n = nullptr;
+    int n_exc = 0;
+    hipError_t e = hipMalloc(&out, sizeof(uint32_t) * ((size_t)n * kWave * 3 + 4));
+    if (e == hipSuccess) e = hipMalloc(&base, sizeof(uint32_t) * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc(&exc, sizeof(int32_t) * (size_t)(n_slabs + 1));
+    if (e == hipSuccess) e = hipMalloc(&d_n, sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(int), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_fr_pack24, dim3((unsigned)(n_slabs + 1)), dim3(256), 0, s, reinterpret_cast<const uint4*>(d_stream32), d_fr_off,
+                           n_slabs, total_chunks, kQ8RowBits, kQ8SlabRows, out, base, exc, d_n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_exc, d_n, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (d_n) (void)hipFree(d_n);
+    if (e != hipSuccess || (int64_t)n_exc * 100 > n_slabs + 99) { // (a one-slab model may be its own exception)
+        if (out) (void)hipFree(out);
+        if (base) (void)hipFree(base);
+        if (exc) (void)hipFree(exc);
+        return e;
+    }
+    p->stream = out; p->base = base; p->exc = exc; p->n_exception_slabs = n_exc;
+    return hipSuccess;
+}
+
 int fr_max_events() { return 1 << 18; }
 bool fr_filter_is_quantised(int32_t n_events) { return fr_use_q8(n_events) && fr_slab_rows_for(n_events) == 8192; }
 int fr_refine_grid(int n_cu) { return n_cu * 8; }
@@ -1291,10 +1431,10 @@ hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64
 
 // Quantised filter: builds the 8-bit table for (logp, cut-off) unless the caller says q8_buf already holds
 // it (table_valid), and runs k_fr_filter_q8. q8_buf holds n_events bytes rounded up to 16.
-hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
-                               uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs, double log_cut,
-                               uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count, int n_cu,
-                               bool table_valid, hipStream_t s) {
+hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, const int64_t* fr_off, int64_t total_chunks,
+                               const double* logp, uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs,
+                               double log_cut, uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count,
+                               int n_cu, bool table_valid, hipStream_t s) {
     const double mag = -log_cut > 1.0 ? -log_cut : 1.0;
     const double inv_step = (double)kQ8Levels / mag;
     // s >= log_cut  ==>  sum(q) <= -log_cut / step; (1 + 2^-28): a hair generous, never too strict
@@ -1347,20 +1487,30 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const int64_t* fr_off, in
 #undef Q8P_GO
     }
     const size_t lds = kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16 + (kQ8SlabRows / 64) * 4;
-    const void* fn = u == 1   ? reinterpret_cast<const void*>(&k_fr_filter_q8<1>)
-                     : u == 2 ? reinterpret_cast<const void*>(&k_fr_filter_q8<2>)
-                     : u == 3 ? reinterpret_cast<const void*>(&k_fr_filter_q8<3>)
-                     : u == 6 ? reinterpret_cast<const void*>(&k_fr_filter_q8<6>)
-                              : reinterpret_cast<const void*>(&k_fr_filter_q8<4>);
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); // per device: every launch
-    if (e != hipSuccess) return e;
     int64_t grid = n_cu;
     if (grid > n_slabs) grid = n_slabs;
     if (grid < 1) grid = 1;
-#define Q8_GO(UU) hipLaunchKernelGGL(k_fr_filter_q8<UU>, dim3((unsigned)grid), dim3(kQ8Threads), lds, s, reinterpret_cast<const uint4*>(stream), fr_off, total_chunks, q8_buf, n_events, n_rows, n_slabs, threshold, cand_list, cand_cnt, cand_count, fr_dbg)
-    if (u == 1) Q8_GO(1); else if (u == 2) Q8_GO(2); else if (u == 3) Q8_GO(3); else if (u == 6) Q8_GO(6); else Q8_GO(4);
+#define Q8_GO(UU, PP)                                                                                                   \
+    do {                                                                                                                \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8<UU, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); /* per device: every launch */ \
+        if (e != hipSuccess) return e;                                                                                  \
+        hipLaunchKernelGGL((k_fr_filter_q8<UU, PP>), dim3((unsigned)grid), dim3(kQ8Threads), lds, s, PP ? p24->stream : stream, \
+                           PP ? p24->base : nullptr, PP ? p24->exc : nullptr, fr_off, total_chunks, q8_buf, n_events, n_rows, \
+                           n_slabs, threshold, cand_list, cand_cnt, cand_count, fr_dbg);                                \
+        return hipGetLastError();                                                                                       \
+    } while (0)
+    if (p24 != nullptr && p24->stream != nullptr) { // the 24-bit form of the same chunks
+        if (u == 2) Q8_GO(2, true);
+        if (u == 3) Q8_GO(3, true);
+        if (u == 6) Q8_GO(6, true);
+        Q8_GO(4, true);
+    }
+    if (u == 1) Q8_GO(1, false);
+    if (u == 2) Q8_GO(2, false);
+    if (u == 3) Q8_GO(3, false);
+    if (u == 6) Q8_GO(6, false);
+    Q8_GO(4, false);
 #undef Q8_GO
-    return hipGetLastError();
 }
 
 hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, const unsigned* cand_cnt, int slab_rows,

@@ -152,7 +152,9 @@ typedef struct canopy_model_info {
     int32_t n_events;
     int32_t max_row_len;
     int64_t device_bytes;       /* bytes of HBM the model holds (canonical CSR + derived layouts) */
-    int64_t stream_bytes;       /* bytes one pass of the wave-stream kernel reads, 0 if not built */
+    int64_t stream_bytes;       /* bytes one pass over the model's derived stream reads (the slab stream in the form the
+                                   filter reads -- 24-bit entries when the model allows --, else the value-scatter or
+                                   wave-slab stream), 0 if none is built */
     int64_t algorithmic_bytes;  /* (R+1)*8 + nnz*4 + E*8: compulsory traffic of one sum-only pass */
 } canopy_model_info;
 
