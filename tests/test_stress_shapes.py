@@ -76,3 +76,38 @@ def test_empty_rows_between_full_slabs(gpu_ctx, oracle):
     row_ptr, col = csr_from_rows(rows)
     p = 10.0 ** rng.uniform(-2, -0.3, size=n_events)
     check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, 1e-4, 20)
+
+
+def test_24_bit_stream_exception_slab_and_rebuild(gpu_ctx, oracle):
+    """The quantised filter's 24-bit stream: three full slabs + a sparse last one (an exception slab: all its rows go to the
+    exact pass), the 32-bit stream rebuilt on demand by the fixed-point pass, and a sparse model that keeps the 32-bit form."""
+    from canopy_amd import _capi, default_params
+    n_events, n_rows = 50_000, 3 * 8192 + 300
+    row_ptr, col = oracle.synth_csr(20250704, n_rows, n_events, 6, n_threads=4)
+    p = oracle.synth_probabilities(20250704, n_events)
+    model = gpu_ctx.upload(row_ptr, col, n_events)
+    model.set_probabilities(p)
+    model.prepare(_capi.KERNEL_FILTER_REFINE)
+    nnz = int(row_ptr[-1])
+    assert model.info().stream_bytes < 3.3 * nnz + 8 * n_events + 4096  # 3 B per entry (+ table, offsets), not 4
+    for cut_off in (1e-8, 1e-5):
+        want = oracle.quantify(row_ptr, col, p, cut_off=cut_off, limit_order=20, n_threads=4, want_rows=False)
+        for kern in (_capi.KERNEL_FILTER_REFINE, _capi.KERNEL_FIXED_SUM, _capi.KERNEL_FILTER_REFINE):
+            got = gpu_ctx.quantify(model, default_params(cut_off=cut_off, kernel=kern))
+            assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row), (cut_off, kern)
+            assert abs(got.rare_event - want.rare_event) <= 1e-12 * want.rare_event
+            assert abs(got.mcub - want.mcub) <= 1e-12 * want.mcub
+    model.close()
+    # 2 entries per row over 1e5 events: a chunk of 256 entries spans ~1560 columns -> the model keeps the 32-bit form
+    n_events = 100_000
+    row_ptr, col = oracle.synth_csr(7, n_rows, n_events, 2, n_threads=4)
+    p = oracle.synth_probabilities(20250704, n_events)
+    model = gpu_ctx.upload(row_ptr, col, n_events)
+    model.set_probabilities(p)
+    model.prepare(_capi.KERNEL_FILTER_REFINE)
+    assert model.info().stream_bytes >= 4 * int(row_ptr[-1])
+    want = oracle.quantify(row_ptr, col, p, cut_off=1e-3, limit_order=20, n_threads=4, want_rows=False)
+    got = gpu_ctx.quantify(model, default_params(cut_off=1e-3, kernel=_capi.KERNEL_FILTER_REFINE))
+    assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row)
+    assert abs(got.rare_event - want.rare_event) <= 1e-12 * want.rare_event
+    model.close()
