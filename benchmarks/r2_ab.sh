@@ -11,12 +11,15 @@ run() { # name, env..., -- args
   shift
   env "${envs[@]}" timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "$name rc=$?"
 }
-run p24_0 X=1 -- --steps 200 --no-also
-run nop24_0 CANOPY_FR_NOP24=1 -- --steps 200 --no-also
-run p24_1 X=1 -- --steps 200 --no-also
-run nop24_1 CANOPY_FR_NOP24=1 -- --steps 200 --no-also
-run p24_2 X=1 -- --steps 200 --no-also
-run nop24_2 CANOPY_FR_NOP24=1 -- --steps 200 --no-also
+# (edit the list below for the experiment at hand: name, environment, --, bench.py arguments)
+run main X=1 -- --steps 200 --no-also
+run main_serial X=1 -- --steps 60 --no-also --no-pipeline
+run main_32bit_stream CANOPY_FR_NOP24=1 -- --steps 200 --no-also
+run cut_off_0 X=1 -- --steps 60 --no-also --cut-off 0
+run shard8 X=1 -- --steps 400 --no-also --shard-of 8
+run shard8_rccl X=1 -- --steps 400 --no-also --shard-of 8 --force-dist
+run e2e5 X=1 -- --no-also --events 200000 --steps 100
+run config2 X=1 -- --no-also --rows 100000 --events 1000 --avg-nnz 4 --steps 1000
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ.get("TAG","ab"))):
