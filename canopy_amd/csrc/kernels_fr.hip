@@ -314,6 +314,16 @@ __device__ __forceinline__ int64_t fr_uload(const int64_t* __restrict__ p) {
     return (int64_t)(((uint64_t)hi << 32) | (uint64_t)lo);
 }
 
+// a wave-uniform pointer pinned to scalar registers: `p + lane_offset` then becomes a load with a scalar base and a 32-bit
+// vector offset instead of a 64-bit vector address the compiler builds with multiply-adds per load
+// (address space 1 = global: the rebuilt pointer must not decay to a generic one, whose loads are flat_load)
+template <typename T>
+__device__ __forceinline__ const T __attribute__((address_space(1))) * fr_uniform_ptr(const T* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const T __attribute__((address_space(1))) *)(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ void fr_barrier() { // LDS drained, then the workgroup barrier (no vmcnt drain)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -476,20 +486,23 @@ template <bool P24>
 __device__ __forceinline__ Q8Chunk q8_load_chunk(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ cbase, int64_t c, int lane) {
     Q8Chunk r;
     if (P24) {
-        const uint32_t* p = stream + (c * kWave + lane) * 3;
+        // (wave-uniform chunk pointer + a 32-bit lane offset: the load takes the pointer from scalar registers; as
+        // `stream + (c * 64 + lane) * 3` the whole index went through 64-bit vector multiplies, two per load)
+        const uint32_t __attribute__((address_space(1))) * chunk = fr_uniform_ptr(stream + c * (int64_t)(kWave * 3));
+        const uint32_t __attribute__((address_space(1))) * p = chunk + (uint32_t)lane * 3u;
         r.x = p[0]; r.y = p[1]; r.z = p[2];
         // The chunk's first column: a VECTOR load (all lanes the same address). Left to the compiler this wave-uniform load
         // becomes s_load_dword, whose completion shares lgkmcnt with the LDS operations and returns out of order: every
         // step then waits (lgkmcnt(0)) for the NEXT step's scalar loads -- a full memory latency -- before its first LDS
         // add. (That is what held the first 24-bit and 16-bit attempts at the 32-bit stream's time.)
         // (address space 1 = global: a generic pointer would become flat_load, which counts in lgkmcnt as well)
-        typedef const uint32_t __attribute__((address_space(1))) * global_u32_ptr;
-        uint64_t a = (uint64_t)(cbase + c);
-        asm volatile("" : "+v"(a));
-        r.w = *(global_u32_ptr)a;
+        // (scalar base + an opaque zero in a vector register: no address arithmetic on the vector ALU)
+        uint32_t zero = 0u;
+        asm volatile("" : "+v"(zero));
+        r.w = fr_uniform_ptr(cbase + c)[zero];
     } else {
-        const uint4 v = reinterpret_cast<const uint4*>(stream)[c * kWave + lane];
-        r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+        const uint32_t __attribute__((address_space(1))) * p = fr_uniform_ptr(stream + c * (int64_t)(kWave * 4)) + (uint32_t)lane * 4u;
+        r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
     }
     return r;
 }
