@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--width", type=int, default=250)
     ap.add_argument("--fan-in", type=int, default=4)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--force-dist", action="store_true", help="world size 1 through the collective path (rehearsal on one GPU)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -34,9 +35,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("gloo")  # control plane only: the exchange itself is libcanopy's RCCL all-reduce
     ctx = canopy_amd.Context(device=local_rank)
+    comm, collective = None, "none (single GPU)"
+    if use_dist:
+        from canopy_amd.distributed import library_comm
+        err = ""
+        try:
+            comm = library_comm(ctx)
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:  # every rank falls back together
+            if comm is not None:
+                comm.close(); comm = None
+            collective = "torch.distributed all_reduce of the hit counts (gloo) [fallback: %s]" % err
+        else:
+            collective = "ncclAllReduce of [hits, trials] issued by libcanopy.so (canopy_comm)"
     dag = layered_dag(20250704, args.events, args.layers, args.width, args.fan_in, atleast_every=5)
     p = np.random.default_rng(20250704).uniform(0.002, 0.1, args.events)
     d = Dag(ctx, dag)
@@ -50,10 +70,15 @@ def main():
         r = d.run(20250704, per_rank, first_sample=rank * per_rank)
         ms += r.elapsed_kernel_ms
     elapsed = time.perf_counter() - t0
-    hits = torch.tensor([r.hits], dtype=torch.int64, device="cuda")
-    if world > 1:
-        dist.all_reduce(hits)  # the single exchange: one u64 sum
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if comm is not None:
+        total_hits = int(comm.mc_fetch().hits)  # every rank holds the sum: the run ended with the library's all-reduce
+    else:
+        hits = torch.tensor([r.hits], dtype=torch.int64)
+        if use_dist:
+            dist.all_reduce(hits)  # the single exchange: one u64 sum
+        total_hits = int(hits.item())
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
         n_gates = len(dag["gate_type"]); total = per_rank * world
@@ -64,9 +89,11 @@ def main():
                                      "n_gates": n_gates, "fan_in": args.fan_in, "layers": args.layers},
                           "event_draws_per_s": total * args.events * args.steps / elapsed,
                           "gate_evals_per_s": total * n_gates * args.steps / elapsed,
-                          "estimate": int(hits.item()) / total, "hits": int(hits.item())}) + "\n").encode())
+                          "estimate": total_hits / total, "hits": total_hits, "collective": collective}) + "\n").encode())
+    if comm is not None:
+        comm.close()
     d.close(); ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
