@@ -734,6 +734,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         }
         if (want_mask && variant == CANOPY_KERNEL_FILTER_REFINE && !ctx->filter_only_request) // the refine pass ORs the exact keep bits into a cleared mask
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, sizeof(uint64_t) * (size_t)(n_words > 0 ? n_words : 1), ctx->stream));
+        bool q8_overlapped = false; // the quantised filter ran with adding / finishing waves: lists in 4096-row units
         if (variant == CANOPY_KERNEL_FIXED_SUM) {
             canopy_model* mm = const_cast<canopy_model*>(m);
             if (!mm->d_fx) HIP_TRY(ctx, hipMalloc(&mm->d_fx, sizeof(uint64_t) * (size_t)(m->n_events > 0 ? m->n_events : 1)));
@@ -764,7 +765,8 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             }
             FrP24 p24;
             p24.stream = m->fr24.stream; p24.base = m->fr24.base; p24.exc = m->fr24.exc;
-            HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, &p24, m->d_fr_off, m->fr_total_chunks, m->d_logp, mm->d_q8, m->n_rows,
+            q8_overlapped = fr_q8_overlapped(&p24, m->n_events, m->max_row_len);
+            HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, &p24, q8_overlapped, m->d_fr_off, m->fr_total_chunks, m->d_logp, mm->d_q8, m->n_rows,
                                              m->n_events, m->n_fr_slabs, a.log_cut, S.d_fr_list, S.d_fr_cnt, S.d_fr_count,
                                              ctx->n_cu, table_valid, lane));
             if (!table_valid && !ctx->capturing) HIP_TRY(ctx, hipStreamSynchronize(lane));
@@ -774,18 +776,19 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
         HIP_TRY(ctx, launch_fr_filter(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, m->d_logp, m->n_rows,
                                       m->n_events, m->n_fr_slabs, cand_cut, S.d_fr_list, S.d_fr_cnt, S.d_fr_count, ctx->n_cu,
                                       lane));
+        int unit_rows = slab_rows, units_per_slab = 1; // list units the exact pass walks
+        if (variant == CANOPY_KERNEL_FIXED_SUM) fx_list_units(m->n_events, &unit_rows, &units_per_slab);
+        else if (q8_overlapped) fr_q8_overlapped_units(&unit_rows, &units_per_slab);
         if (ctx->filter_only_request && variant == CANOPY_KERNEL_FILTER_REFINE) {
             // the batch path lists, marks and compacts the candidates itself (kernels_batch.hip): nothing else to run
             ctx->filter_only_done = true;
-            ctx->filter_only_slab_rows = slab_rows;
-            ctx->filter_only_slabs = m->n_fr_slabs;
+            ctx->filter_only_slab_rows = unit_rows;
+            ctx->filter_only_slabs = m->n_fr_slabs * units_per_slab;
             ctx->last_variant = variant;
             ctx->last_set = set;
             ctx->fr_pending_id = 0; // its candidate count is consumed by the batch, not by AUTO's feedback
             return CANOPY_OK;
         }
-        int unit_rows = slab_rows, units_per_slab = 1; // list units the exact pass walks
-        if (variant == CANOPY_KERNEL_FIXED_SUM) fx_list_units(m->n_events, &unit_rows, &units_per_slab);
         const int64_t n_units = m->n_fr_slabs * units_per_slab;
         const int64_t g_need = (2 * n_units + 3) / 4 > 0 ? (2 * n_units + 3) / 4 : 1; // two waves per unit, four per workgroup
         if ((int64_t)grid > g_need) grid = (int)g_need; // a small shard does not pay for 2048 workgroups' records

@@ -291,7 +291,10 @@ __global__ __launch_bounds__(256) void k_fr_pack24(const uint4* __restrict__ str
             const bool pad = rl >= (uint32_t)slab_rows;
             const uint32_t off = pad ? 0u : col - col0; // ascending columns: col >= col0
             bad = bad || off >= kP24ColSpan;
-            pk[k] = ((off & (kP24ColSpan - 1u)) << 14) | rl;
+            // padding: sink row 8192 + 2 k (the overlapped filter packs two rows per LDS word: sink k = the low half of
+            // word 4096 + k; the plain filter keeps 128 sink slots)
+            const uint32_t rl24 = pad ? (uint32_t)slab_rows + 2u * ((rl - (uint32_t)slab_rows) & 63u) : rl;
+            pk[k] = ((off & (kP24ColSpan - 1u)) << 14) | rl24;
         }
         uint32_t* o = out24 + (c * kWave + lane) * 3;
         o[0] = pk[0] | (pk[1] << 24);
@@ -476,7 +479,8 @@ __global__ __launch_bounds__(256) void k_fr_q8_table(const double* __restrict__ 
 
 constexpr int kQ8SlabRows = 8192, kQ8RowBits = 14, kQ8Waves = 16, kQ8Threads = kQ8Waves * kWave;
 constexpr uint32_t kQ8RowMask = (1u << kQ8RowBits) - 1;
-constexpr size_t kQ8SumsBytes = (size_t)(kQ8SlabRows + 64) * 4;
+constexpr int kQ8Sinks = 128; // (the 24-bit stream's padding entries use the even ones: 8192 + 2 k)
+constexpr size_t kQ8SumsBytes = (size_t)(kQ8SlabRows + kQ8Sinks) * 4;
 
 struct Q8Chunk { // one lane's share of a chunk in flight: 32-bit form x y z w = four entries; 24-bit form x y z = 12 packed bytes, w = the chunk's first column
     uint32_t x, y, z, w;
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint32_t* __r
         }                                                                                           \
     }
     FR_FIRST_CHUNKS((int64_t)blockIdx.x)
-    for (int i = tid; i < kQ8SlabRows + 64; i += kQ8Threads) sums[i] = 0u;
+    for (int i = tid; i < kQ8SlabRows + kQ8Sinks; i += kQ8Threads) sums[i] = 0u;
     { // the table, 16 bytes per lane per step (its buffer is padded to a multiple of 16)
         const uint4* src = reinterpret_cast<const uint4*>(q8);
         uint4* dst = reinterpret_cast<uint4*>(tab);
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint32_t* __r
 #pragma unroll
             for (int i = 0; i < NI; ++i) s_cnt[i * kQ8Waves + wave] = (unsigned)__builtin_popcountll(m[i]);
         }
-        if (tid < 64) sums[kQ8SlabRows + tid] = 0u; // the sink
+        if (tid < kQ8Sinks) sums[kQ8SlabRows + tid] = 0u; // the sinks
         fr_barrier();
         const unsigned no_flags[NI] = {};
         const unsigned total = fr_emit_candidates<NI, kQ8Waves>(m, no_flags, s_cnt, lane, wave, tid, cand_list + s * kQ8SlabRows);
@@ -626,6 +630,154 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint32_t* __r
     }
 #undef FR_FIRST_CHUNKS
     if (tid == 0 && n_cand) atomicAdd(cand_count, n_cand); // one global atomic per workgroup, as in k_fr_filter
+}
+
+// ---- pass A, quantised form, the slab's end step folded into the next slabs' work (24-bit stream, rows of <= 257 entries)
+// k_fr_filter_q8 ends every slab with a workgroup-wide step (two barriers, the ballots over the 8192 sums, the ordered
+// candidate list) during which nothing is added: with the 24-bit stream that step is what separates the pass from the HBM
+// time of its stream (end step removed: 0.368 -> 0.295 ms at config 3). Here the row sums are PACKED two to a 32-bit word
+// (u16 each: a row of L entries sums to <= 255 L, so L <= 257 cannot carry into its neighbour), which makes room for TWO
+// slabs of sums beside the table, and the end step of slab k is spread over the two following iterations of all 16 waves:
+//   iteration k    every wave adds its chunks of slab k into buffer k & 1;                               barrier
+//   iteration k+1  every wave takes ITS 512 rows of slab k out of that buffer (threshold, ballots kept in registers,
+//                  clear), publishes its count, then adds slab k+1 into the other buffer;                barrier
+//   iteration k+2  every wave reads the 16 counts of slab k and writes its candidates at their place in the slab's list.
+// One barrier per slab, no wave ever waits for the list of a slab, the lists are the same ascending lists as before.
+// (Dedicated finishing waves, 14 + 2, were measured first: 0.343 ms -- the pass is bound by what ITS adding waves get
+// through, and two fewer of them cost what the hidden end step gained; 15 + 1: 0.60, one wave cannot finish 8192 rows.)
+constexpr int kQ8oBufWords = kQ8SlabRows / 2 + 64;
+constexpr size_t kQ8oSumsBytes = (size_t)2 * kQ8oBufWords * 4;
+constexpr int kQ8oMaxRowLen = 257;
+constexpr int kQ8oWaveRows = kQ8SlabRows / kQ8Waves; // 512 rows = 256 words = 4 words per lane
+
+template <int U>
+__global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8o(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ cbase,
+                                                              const int32_t* __restrict__ exc, const int64_t* __restrict__ fr_off,
+                                                              int64_t total_chunks, const uint8_t* __restrict__ q8, int32_t n_events,
+                                                              int64_t n_rows, int64_t n_slabs, int threshold,
+                                                              uint16_t* __restrict__ cand_list, unsigned* __restrict__ cand_cnt,
+                                                              unsigned long long* __restrict__ cand_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* bufs = reinterpret_cast<unsigned*>(smem);                                  // [2][kQ8oBufWords]
+    uint8_t* tab = reinterpret_cast<uint8_t*>(smem + kQ8oSumsBytes);
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(smem + kQ8oSumsBytes + (((size_t)n_events + 15) / 16) * 16); // [2][16]
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int64_t G = (int64_t)gridDim.x;
+    Q8Chunk q[U];
+#define FRO_FIRST_CHUNKS(SLAB)                                                                      \
+    if ((SLAB) < n_slabs) {                                                                         \
+        const int64_t f0 = fr_uload(fr_off + (SLAB));                                               \
+        const int64_t f1 = __builtin_amdgcn_readfirstlane(exc[(SLAB)]) != 0 ? f0 : fr_uload(fr_off + (SLAB) + 1); \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                             \
+            const int64_t c = f0 + wave + (int64_t)u * kQ8Waves;                                    \
+            q[u] = q8_load_chunk<true>(stream, cbase, c < f1 ? c : total_chunks, lane);             \
+        }                                                                                           \
+    }
+    FRO_FIRST_CHUNKS((int64_t)blockIdx.x)
+    for (int i = tid; i < 2 * kQ8oBufWords; i += kQ8Threads) bufs[i] = 0u;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(q8);
+        uint4* dst = reinterpret_cast<uint4*>(tab);
+        for (int i = tid; i < (n_events + 15) / 16; i += kQ8Threads) dst[i] = src[i];
+    }
+    fr_barrier();
+
+    unsigned long long n_cand = 0;                    // wave 0: candidates of the slabs this workgroup listed
+    unsigned long long mlo[4] = {0, 0, 0, 0}, mhi[4] = {0, 0, 0, 0}; // the ballots of the slab whose counts are published (wave-uniform)
+    int64_t s_count = -1, s_emit = -1;                // slab to take out of its buffer / slab to list, this iteration
+    bool all_count = false;
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    int it = 0;
+    for (int64_t s = (int64_t)blockIdx.x;; s += G, ++it) {
+        const bool have = s < n_slabs;
+        // an exception slab of the 24-bit form: no chunk is read, every row goes to the exact pass
+        const bool all_rows = have && __builtin_amdgcn_readfirstlane(exc[have ? s : 0]) != 0;
+        if (s_emit >= 0) { // ---- the list of slab s_emit: this wave's candidates behind those of the waves before it
+            const unsigned* cnt = s_cnt + ((it - 1) & 1) * kQ8Waves; // published during the previous iteration
+            unsigned before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < kQ8Waves; ++w) {
+                const unsigned c = cnt[w];
+                before += w < wave ? c : 0u;
+                total += c;
+            }
+            uint16_t* seg = cand_list + s_emit * (int64_t)kQ8SlabRows;
+            unsigned n_list = before;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long a = mlo[u], b = mhi[u];
+                if ((a | b) != 0ULL) { // wave-uniform
+                    const int rl = wave * kQ8oWaveRows + 2 * (u * kWave + lane); // the word's low row, local to the slab
+                    const bool k_lo = (a >> lane) & 1ULL, k_hi = (b >> lane) & 1ULL;
+                    const unsigned pre = n_list + (unsigned)__builtin_popcountll(a & below) + (unsigned)__builtin_popcountll(b & below);
+                    if (k_lo) seg[pre] = (uint16_t)rl;
+                    if (k_hi) seg[pre + (k_lo ? 1u : 0u)] = (uint16_t)(rl + 1);
+                    n_list += (unsigned)__builtin_popcountll(a) + (unsigned)__builtin_popcountll(b);
+                }
+            }
+            if (tid == 0) cand_cnt[s_emit] = total;
+            n_cand += total;
+        }
+        if (s_count >= 0) { // ---- this wave's 512 rows of slab s_count out of its buffer; the count is published
+            unsigned* sums = bufs + (size_t)((it - 1) & 1) * kQ8oBufWords;
+            const int64_t r0 = s_count * kQ8SlabRows + (int64_t)wave * kQ8oWaveRows;
+            unsigned d[4], n_w = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = wave * (kQ8oWaveRows / 2) + u * kWave + lane;
+                d[u] = sums[w];
+                sums[w] = 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t r = r0 + 2 * (u * kWave + lane);
+                const bool k_lo = r < n_rows && (all_count || (int)(d[u] & 0xffffu) <= threshold);
+                const bool k_hi = r + 1 < n_rows && (all_count || (int)(d[u] >> 16) <= threshold);
+                mlo[u] = __ballot(k_lo);
+                mhi[u] = __ballot(k_hi);
+                n_w += (unsigned)__builtin_popcountll(mlo[u]) + (unsigned)__builtin_popcountll(mhi[u]);
+            }
+            if (wave == 0) sums[kQ8SlabRows / 2 + lane] = 0u; // the sinks
+            if (lane == 0) s_cnt[(it & 1) * kQ8Waves + wave] = n_w;
+        }
+        if (have) { // ---- add slab s into buffer it & 1
+            unsigned* sums = bufs + (size_t)(it & 1) * kQ8oBufWords;
+            const int64_t c0 = fr_uload(fr_off + s);
+            const int64_t c1 = all_rows ? c0 : fr_uload(fr_off + s + 1);
+            for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * kQ8Waves) {
+                Q8Chunk qn[U]; // next step's chunks first: nothing else is in the vector-memory queue
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t c = cb + (int64_t)(U + u) * kQ8Waves;
+                    qn[u] = q8_load_chunk<true>(stream, cbase, c < c1 ? c : total_chunks, lane);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint32_t col[4], row[4];
+                    q8_decode<true>(q[u], col, row);
+                    unsigned v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = tab[col[k]];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) // word row / 2, half row & 1
+                        __hip_atomic_fetch_add(&sums[row[k] >> 1], v[k] << ((row[k] & 1u) << 4), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) q[u] = qn[u];
+            }
+            FRO_FIRST_CHUNKS(s + G) // the next slab's stream starts before this slab's barrier
+        }
+        s_emit = s_count;           // (its counts are published once this iteration's barrier is passed)
+        s_count = have ? s : -1;
+        all_count = all_rows;
+        if (!have && s_emit < 0) break; // nothing left in flight (no barrier needed: nobody reads anything of ours any more)
+        fr_barrier();
+    }
+#undef FRO_FIRST_CHUNKS
+    if (tid == 0 && n_cand) atomicAdd(cand_count, n_cand); // one global atomic per workgroup
 }
 
 // ---- pass A, quantised form, wide event spaces (112 K < E <= 2^18): one part of the table resident per sweep ----
@@ -651,7 +803,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8p(const uint4* __res
     const int H = P.H;
     constexpr int NI = kQ8SlabRows / kQ8Threads;
     uint4 q[U];
-    for (int i = tid; i < kQ8SlabRows + 64; i += kQ8Threads) sums[i] = 0u;
+    for (int i = tid; i < kQ8SlabRows + kQ8Sinks; i += kQ8Threads) sums[i] = 0u;
     unsigned long long n_cand = 0;
     for (int h = 0; h < H; ++h) {
         const int a0 = P.c_lo[h] & ~15, a1 = P.c_lo[h + 1]; // the table bytes of this part (16-byte aligned start)
@@ -718,7 +870,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8p(const uint4* __res
                     sums[rl] = 0u;
                     part_sums[rl] = (uint16_t)(sv < 65535u ? sv : 65535u);
                 }
-                if (tid < 64) sums[kQ8SlabRows + tid] = 0u; // the sink
+                if (tid < kQ8Sinks) sums[kQ8SlabRows + tid] = 0u; // the sinks
                 fr_barrier();
                 continue;
             }
@@ -734,7 +886,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8p(const uint4* __res
 #pragma unroll
                 for (int i = 0; i < NI; ++i) s_cnt[i * kQ8Waves + wave] = (unsigned)__builtin_popcountll(m[i]);
             }
-            if (tid < 64) sums[kQ8SlabRows + tid] = 0u; // the sink
+            if (tid < kQ8Sinks) sums[kQ8SlabRows + tid] = 0u; // the sinks
             fr_barrier();
             const unsigned no_flags[NI] = {};
             const unsigned total = fr_emit_candidates<NI, kQ8Waves>(m, no_flags, s_cnt, lane, wave, tid, cand_list + s * kQ8SlabRows);
@@ -1444,7 +1596,15 @@ hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64
 
 // Quantised filter: builds the 8-bit table for (logp, cut-off) unless the caller says q8_buf already holds
 // it (table_valid), and runs k_fr_filter_q8. q8_buf holds n_events bytes rounded up to 16.
-hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, const int64_t* fr_off, int64_t total_chunks,
+// overlapped: run k_fr_filter_q8o (fr_q8_overlapped says when it applies)
+bool fr_q8_overlapped(const FrP24* p24, int32_t n_events, int32_t max_row_len) {
+    static const bool off = getenv("CANOPY_FR_NOOVERLAP") != nullptr; // tuning only
+    return !off && p24 != nullptr && p24->stream != nullptr && max_row_len <= kQ8oMaxRowLen && fr_parts_for(n_events) == 1 &&
+           kQ8oSumsBytes + (((size_t)n_events + 15) / 16) * 16 + 2 * kQ8Waves * 4 <= (size_t)160 * 1024;
+}
+void fr_q8_overlapped_units(int* unit_rows, int* units_per_slab) { *unit_rows = kQ8SlabRows; *units_per_slab = 1; } // (slab lists, as the plain filter's)
+
+hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool overlapped, const int64_t* fr_off, int64_t total_chunks,
                                const double* logp, uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs,
                                double log_cut, uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count,
                                int n_cu, bool table_valid, hipStream_t s) {
@@ -1512,6 +1672,24 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, const i
                            n_slabs, threshold, cand_list, cand_cnt, cand_count, fr_dbg);                                \
         return hipGetLastError();                                                                                       \
     } while (0)
+    if (overlapped) { // adding and finishing waves side by side (list units of 4096 rows)
+        if (p24 == nullptr || p24->stream == nullptr) return hipErrorInvalidValue;
+        const size_t lds_o = kQ8oSumsBytes + (((size_t)n_events + 15) / 16) * 16 + 2 * kQ8Waves * 4;
+        if (lds_o > (size_t)160 * 1024) return hipErrorInvalidValue;
+#define Q8O_GO(UU)                                                                                                      \
+        do {                                                                                                            \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8o<UU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return e;                                                                              \
+            hipLaunchKernelGGL((k_fr_filter_q8o<UU>), dim3((unsigned)grid), dim3(kQ8Threads), lds_o, s, p24->stream, p24->base, p24->exc, \
+                               fr_off, total_chunks, q8_buf, n_events, n_rows, n_slabs, threshold, cand_list, cand_cnt, cand_count); \
+            return hipGetLastError();                                                                                   \
+        } while (0)
+        if (u == 2) Q8O_GO(2);
+        if (u == 3) Q8O_GO(3);
+        if (u == 6) Q8O_GO(6);
+        Q8O_GO(4);
+#undef Q8O_GO
+    }
     if (p24 != nullptr && p24->stream != nullptr) { // the 24-bit form of the same chunks
         if (u == 2) Q8_GO(2, true);
         if (u == 3) Q8_GO(3, true);
