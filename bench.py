@@ -277,6 +277,9 @@ def main():
 
     variant = ctx.last_kernel_variant()  # what AUTO resolved to, reported by the library
     kernel_label = KERNEL_LABELS.get(variant, "?")
+    if variant == 5 and info.n_events <= 112 * 1024 and info.stream_bytes < 3.6 * info.nnz + 8 * info.n_events and info.max_row_len <= 257:
+        kernel_label = ("k_fr_filter_q8o + k_fr_refine (quantised conservative filter over the 24-bit slab stream, the slab's end step "
+                        "folded into the next iterations; then exact refine)")
     if variant == 5 and info.n_events > 112 * 1024:
         kernel_label = "k_fr_filter_q8p + k_fr_refine (quantised filter, one column part of the table resident per sweep; then exact refine)"
 
