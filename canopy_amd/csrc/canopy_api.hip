@@ -766,7 +766,7 @@ canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* m, cons
             FrP24 p24;
             p24.stream = m->fr24.stream; p24.base = m->fr24.base; p24.exc = m->fr24.exc;
             q8_overlapped = fr_q8_overlapped(&p24, m->n_events, m->max_row_len);
-            HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, &p24, q8_overlapped, m->d_fr_off, m->fr_total_chunks, m->d_logp, mm->d_q8, m->n_rows,
+            HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, &p24, q8_overlapped, m->max_row_len, m->d_fr_off, m->fr_total_chunks, m->d_logp, mm->d_q8, m->n_rows,
                                              m->n_events, m->n_fr_slabs, a.log_cut, S.d_fr_list, S.d_fr_cnt, S.d_fr_count,
                                              ctx->n_cu, table_valid, lane));
             if (!table_valid && !ctx->capturing) HIP_TRY(ctx, hipStreamSynchronize(lane));

@@ -287,8 +287,8 @@ hipError_t fr_build_pack24(const uint32_t* d_stream32, const int64_t* d_fr_off, 
                            FrP24Owned* p, hipStream_t s);
 bool fr_q8_overlapped(const FrP24* p24, int32_t n_events, int32_t max_row_len);
 void fr_q8_overlapped_units(int* unit_rows, int* units_per_slab);
-hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool overlapped, const int64_t* fr_off, int64_t total_chunks,
-                               const double* logp, uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs,
+hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool overlapped, int32_t max_row_len, const int64_t* fr_off,
+                               int64_t total_chunks, const double* logp, uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs,
                                double log_cut, uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count,
                                int n_cu, bool table_valid, hipStream_t s);
 // flagged: the lists come from launch_fx_sum (flag bits 15 / 14 per entry); records go to block_partials[part_offset + block]

@@ -898,6 +898,166 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8p(const uint4* __res
     if (tid == 0 && n_cand) atomicAdd(cand_count, n_cand);
 }
 
+// ---- pass A, quantised form, wide event spaces, the end step folded into the next iterations (rows of <= 257 entries) ----
+// k_fr_filter_q8p with k_fr_filter_q8o's structure: packed u16 row sums in two buffers, ONE barrier per (slab, part); every
+// wave takes its 512 rows of the previous (slab, part) out of the other buffer after the barrier -- parks them as they
+// are (packed words, in the slab's list segment) when more parts follow, or thresholds them and publishes its count after
+// the last part -- while its loads of the current (slab, part) are in flight, and lists its candidates one iteration later.
+template <int U>
+__global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8po(const uint4* __restrict__ stream, const int64_t* __restrict__ fr_off,
+                                                               int64_t total_chunks, const uint8_t* __restrict__ q8, Q8Parts P,
+                                                               int64_t n_rows, int64_t n_slabs, int threshold,
+                                                               uint16_t* __restrict__ cand_list, unsigned* __restrict__ cand_cnt,
+                                                               unsigned long long* __restrict__ cand_count, size_t tab_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* bufs = reinterpret_cast<unsigned*>(smem);                                  // [2][kQ8oBufWords]
+    uint8_t* tab = reinterpret_cast<uint8_t*>(smem + kQ8oSumsBytes);
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(smem + kQ8oSumsBytes + tab_bytes);     // [2][16]
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int64_t G = (int64_t)gridDim.x;
+    const int H = P.H;
+    uint4 q[U];
+    for (int i = tid; i < 2 * kQ8oBufWords; i += kQ8Threads) bufs[i] = 0u;
+    unsigned long long n_cand = 0;
+    unsigned long long mlo[4] = {0, 0, 0, 0}, mhi[4] = {0, 0, 0, 0};
+    int64_t s_take = -1, s_emit = -1; // slab whose (previous) part is taken out of its buffer / slab to list, this iteration
+    bool take_last = false;           // ... and whether that part was the slab's last
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    int it = 0;
+    for (int h = 0; h <= H; ++h) { // h = H: the drain iterations (nothing to add any more)
+        const int a0 = h < H ? (P.c_lo[h] & ~15) : 0, a1 = h < H ? P.c_lo[h + 1] : 0;
+#define FRPO_FIRST_CHUNKS(SLAB)                                                                     \
+        if (h < H && (SLAB) < n_slabs) {                                                            \
+            const int64_t f0 = fr_uload(fr_off + (SLAB) * H + h), f1 = fr_uload(fr_off + (SLAB) * H + h + 1); \
+            _Pragma("unroll") for (int u = 0; u < U; ++u) {                                         \
+                const int64_t c = f0 + wave + (int64_t)u * kQ8Waves;                                \
+                q[u] = stream[(c < f1 ? c : total_chunks) * kWave + lane];                          \
+            }                                                                                       \
+        }
+        FRPO_FIRST_CHUNKS((int64_t)blockIdx.x)
+        fr_barrier(); // everybody is done adding with the previous part's table (and the first buffers are cleared)
+        if (h < H) {
+            const uint4* src = reinterpret_cast<const uint4*>(q8 + a0);
+            uint4* dst = reinterpret_cast<uint4*>(tab);
+            for (int i = tid; i < (a1 - a0 + 15) / 16; i += kQ8Threads) dst[i] = src[i];
+        }
+        fr_barrier();
+        for (int64_t s = (int64_t)blockIdx.x;; s += G, ++it) {
+            const bool have = h < H && s < n_slabs;
+            if (!have && s_take < 0 && s_emit < 0) break; // (workgroup-uniform)
+            if (h == H && s_take < 0 && s_emit < 0) break;
+            if (s_emit >= 0) { // ---- the list of slab s_emit
+                const unsigned* cnt = s_cnt + ((it - 1) & 1) * kQ8Waves;
+                unsigned before = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < kQ8Waves; ++w) {
+                    const unsigned c = cnt[w];
+                    before += w < wave ? c : 0u;
+                    total += c;
+                }
+                uint16_t* seg = cand_list + s_emit * (int64_t)kQ8SlabRows;
+                unsigned n_list = before;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long a = mlo[u], b = mhi[u];
+                    if ((a | b) != 0ULL) {
+                        const int rl = wave * kQ8oWaveRows + 2 * (u * kWave + lane);
+                        const bool k_lo = (a >> lane) & 1ULL, k_hi = (b >> lane) & 1ULL;
+                        const unsigned pre = n_list + (unsigned)__builtin_popcountll(a & below) + (unsigned)__builtin_popcountll(b & below);
+                        if (k_lo) seg[pre] = (uint16_t)rl;
+                        if (k_hi) seg[pre + (k_lo ? 1u : 0u)] = (uint16_t)(rl + 1);
+                        n_list += (unsigned)__builtin_popcountll(a) + (unsigned)__builtin_popcountll(b);
+                    }
+                }
+                if (tid == 0) cand_cnt[s_emit] = total;
+                n_cand += total;
+            }
+            s_emit = -1;
+            // the sums of the earlier parts of the CURRENT slab: requested now, added after its chunk loop (adds commute)
+            unsigned resume[4] = {0u, 0u, 0u, 0u};
+            if (have && h > 0) {
+                const unsigned* parked = reinterpret_cast<const unsigned*>(cand_list + s * (int64_t)kQ8SlabRows);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) resume[u] = parked[wave * (kQ8oWaveRows / 2) + u * kWave + lane];
+            }
+            if (s_take >= 0) { // ---- this wave's 512 rows of the previous (slab, part) out of its buffer
+                unsigned* sums = bufs + (size_t)((it - 1) & 1) * kQ8oBufWords;
+                unsigned d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int w = wave * (kQ8oWaveRows / 2) + u * kWave + lane;
+                    d[u] = sums[w];
+                    sums[w] = 0u;
+                }
+                if (wave == 0) sums[kQ8SlabRows / 2 + lane] = 0u; // the sinks
+                if (!take_last) { // more parts follow: park the packed words in the slab's (not yet written) list segment
+                    unsigned* parked = reinterpret_cast<unsigned*>(cand_list + s_take * (int64_t)kQ8SlabRows);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) parked[wave * (kQ8oWaveRows / 2) + u * kWave + lane] = d[u];
+                } else {
+                    const int64_t r0 = s_take * kQ8SlabRows + (int64_t)wave * kQ8oWaveRows;
+                    unsigned n_w = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t r = r0 + 2 * (u * kWave + lane);
+                        const bool k_lo = r < n_rows && (int)(d[u] & 0xffffu) <= threshold;
+                        const bool k_hi = r + 1 < n_rows && (int)(d[u] >> 16) <= threshold;
+                        mlo[u] = __ballot(k_lo);
+                        mhi[u] = __ballot(k_hi);
+                        n_w += (unsigned)__builtin_popcountll(mlo[u]) + (unsigned)__builtin_popcountll(mhi[u]);
+                    }
+                    if (lane == 0) s_cnt[(it & 1) * kQ8Waves + wave] = n_w;
+                    s_emit = s_take; // listed next iteration, once every wave's count is published
+                }
+            }
+            s_take = -1;
+            if (have) { // ---- add (slab s, part h) into buffer it & 1
+                unsigned* sums = bufs + (size_t)(it & 1) * kQ8oBufWords;
+                const int64_t c0 = fr_uload(fr_off + s * H + h), c1 = fr_uload(fr_off + s * H + h + 1);
+                for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * kQ8Waves) {
+                    uint4 qn[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int64_t c = cb + (int64_t)(U + u) * kQ8Waves;
+                        qn[u] = stream[(c < c1 ? c : total_chunks) * kWave + lane];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                        unsigned v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int col = (int)(e[k] >> kQ8RowBits);
+                            v[k] = tab[col >= a0 ? col - a0 : 0]; // (padding entries carry column 0 and a sink row)
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t row = e[k] & kQ8RowMask;
+                            __hip_atomic_fetch_add(&sums[row >> 1], v[k] << ((row & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) q[u] = qn[u];
+                }
+                FRPO_FIRST_CHUNKS(s + G)
+                if (h > 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        __hip_atomic_fetch_add(&sums[wave * (kQ8oWaveRows / 2) + u * kWave + lane], resume[u], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                s_take = s;
+                take_last = h + 1 == H;
+            }
+            fr_barrier();
+        }
+#undef FRPO_FIRST_CHUNKS
+    }
+    if (tid == 0 && n_cand) atomicAdd(cand_count, n_cand);
+}
+
 // ---- pass B ------------------------------------------------------------------------------------------
 // Two waves per slab walk its candidate list, 64 candidates per trip each: a lane sums one candidate row
 // from the canonical CSR in CSR order. Fixed wave <- (slab, half) and lane <- list position assignment =>
@@ -1604,8 +1764,8 @@ bool fr_q8_overlapped(const FrP24* p24, int32_t n_events, int32_t max_row_len) {
 }
 void fr_q8_overlapped_units(int* unit_rows, int* units_per_slab) { *unit_rows = kQ8SlabRows; *units_per_slab = 1; } // (slab lists, as the plain filter's)
 
-hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool overlapped, const int64_t* fr_off, int64_t total_chunks,
-                               const double* logp, uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs,
+hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool overlapped, int32_t max_row_len, const int64_t* fr_off,
+                               int64_t total_chunks, const double* logp, uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs,
                                double log_cut, uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count,
                                int n_cu, bool table_valid, hipStream_t s) {
     const double mag = -log_cut > 1.0 ? -log_cut : 1.0;
@@ -1644,6 +1804,9 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
                                fr_off, total_chunks, q8_buf, P, n_rows, n_slabs, threshold, cand_list, cand_cnt, cand_count, part_max); \
             return hipGetLastError();                                                                                  \
         } while (0)
+        static const bool no_fold = getenv("CANOPY_FR_NOOVERLAP") != nullptr; // tuning only
+        const size_t lds_po = kQ8oSumsBytes + part_max + 2 * kQ8Waves * 4;
+        const bool folded = !no_fold && max_row_len <= kQ8oMaxRowLen && lds_po <= (size_t)160 * 1024;
         // chunks in flight per wave: a (slab, part) holds total_chunks / (n_slabs * H) chunks on average (97 at E = 2e5); with
         // U = 4 its loop is one full step of 64 chunks and a second, nearly empty one that costs the same latency; U = 6
         // covers it in one step (measured at E = 2e5: 0.6245 -> 0.598 ms; U = 8 0.616)
@@ -1653,6 +1816,19 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
             const double avg = n_slabs > 0 ? (double)total_chunks / ((double)n_slabs * H) : 0.0;
             up = (avg * 1.1 > 4.0 * kQ8Waves && avg * 1.1 <= 6.0 * kQ8Waves) ? 6 : 4;
         }
+#define Q8PO_GO(UU)                                                                                                    \
+        do {                                                                                                           \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8po<UU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return e;                                                                             \
+            hipLaunchKernelGGL(k_fr_filter_q8po<UU>, dim3((unsigned)gp), dim3(kQ8Threads), lds_po, s, reinterpret_cast<const uint4*>(stream), \
+                               fr_off, total_chunks, q8_buf, P, n_rows, n_slabs, threshold, cand_list, cand_cnt, cand_count, part_max); \
+            return hipGetLastError();                                                                                  \
+        } while (0)
+        if (folded) {
+            if (up == 6) Q8PO_GO(6);
+            Q8PO_GO(4);
+        }
+#undef Q8PO_GO
         if (up == 2) Q8P_GO(2);
         if (up == 3) Q8P_GO(3);
         if (up == 6) Q8P_GO(6);
