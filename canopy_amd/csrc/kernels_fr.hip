@@ -746,29 +746,40 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8o(const uint32_t* __
             unsigned* sums = bufs + (size_t)(it & 1) * kQ8oBufWords;
             const int64_t c0 = fr_uload(fr_off + s);
             const int64_t c1 = all_rows ? c0 : fr_uload(fr_off + s + 1);
-            for (int64_t cb = c0 + wave; cb < c1; cb += (int64_t)U * kQ8Waves) {
-                Q8Chunk qn[U]; // next step's chunks first: nothing else is in the vector-memory queue
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int64_t c = cb + (int64_t)(U + u) * kQ8Waves;
-                    qn[u] = q8_load_chunk<true>(stream, cbase, c < c1 ? c : total_chunks, lane);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    uint32_t col[4], row[4];
-                    q8_decode<true>(q[u], col, row);
-                    unsigned v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = tab[col[k]];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) // word row / 2, half row & 1
-                        __hip_atomic_fetch_add(&sums[row[k] >> 1], v[k] << ((row[k] & 1u) << 4), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) q[u] = qn[u];
+            // two register sets in ping-pong (a copy "q = qn" at the end of the body makes the compiler wait for all of the
+            // next chunks every iteration)
+#define Q8O_HALF(QC, QN, CB)                                                                                           \
+            {                                                                                                          \
+                _Pragma("unroll") for (int u = 0; u < U; ++u) { /* next step's chunks first */                          \
+                    const int64_t c = (CB) + (int64_t)(U + u) * kQ8Waves;                                              \
+                    QN[u] = q8_load_chunk<true>(stream, cbase, c < c1 ? c : total_chunks, lane);                       \
+                }                                                                                                      \
+                _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                        \
+                    uint32_t col[4], row[4];                                                                           \
+                    q8_decode<true>(QC[u], col, row);                                                                  \
+                    unsigned v[4];                                                                                     \
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) v[k] = tab[col[k]];                                  \
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) /* word row / 2, half row & 1 */                     \
+                        __hip_atomic_fetch_add(&sums[row[k] >> 1], v[k] << ((row[k] & 1u) << 4), __ATOMIC_RELAXED,     \
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);                                          \
+                }                                                                                                      \
             }
-            FRO_FIRST_CHUNKS(s + G) // the next slab's stream starts before this slab's barrier
+            {
+                Q8Chunk q2[U];
+                bool in_q = true; // which set holds the chunks requested last (after the loop: the no-op chunks past the end)
+                for (int64_t cb = c0 + wave; cb < c1;) {
+                    Q8O_HALF(q, q2, cb)
+                    cb += (int64_t)U * kQ8Waves;
+                    in_q = false;
+                    if (cb >= c1) break;
+                    Q8O_HALF(q2, q, cb)
+                    cb += (int64_t)U * kQ8Waves;
+                    in_q = true;
+                }
+                (void)in_q;
+            }
+#undef Q8O_HALF
+            FRO_FIRST_CHUNKS(s + G) // the next slab's stream starts before this slab's barrier (always into q)
         }
         s_emit = s_count;           // (its counts are published once this iteration's barrier is passed)
         s_count = have ? s : -1;
