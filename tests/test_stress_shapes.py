@@ -111,3 +111,30 @@ def test_24_bit_stream_exception_slab_and_rebuild(gpu_ctx, oracle):
     assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row)
     assert abs(got.rare_event - want.rare_event) <= 1e-12 * want.rare_event
     model.close()
+
+
+@pytest.mark.parametrize("long_len", [257, 258])
+def test_packed_row_sums_do_not_carry_into_the_neighbour(gpu_ctx, oracle, long_len):
+    """The folded filter packs two rows' u16 sums into one LDS word: a row of 257 entries that all clamp at 255 sums to
+    exactly 65535 (no carry into the row beside it); 258 entries take the plain filter. Every second row is such a row, the
+    rows between them survive the cut-off with one likely event."""
+    rng = np.random.default_rng(21)
+    n_events = 600
+    rows = []
+    for i in range(9000):
+        if i % 2 == 0:
+            rows.append(sorted(int(c) for c in rng.choice(np.arange(100, n_events), size=long_len, replace=False)))
+        else:
+            rows.append([int(rng.integers(0, 100))])
+    row_ptr, col = csr_from_rows(rows)
+    p = np.full(n_events, 1e-300)  # -log p far beyond the table's range: every such entry clamps at 255
+    p[:100] = rng.uniform(0.2, 0.9, size=100)
+    from canopy_amd import _capi, default_params
+    want = oracle.quantify(row_ptr, col, p, cut_off=1e-8, limit_order=0, n_threads=4, want_rows=False)
+    assert int(want.n_kept) == 4500
+    model = gpu_ctx.upload(row_ptr, col, n_events)
+    model.set_probabilities(p)
+    got = gpu_ctx.quantify(model, default_params(cut_off=1e-8, limit_order=0, kernel=_capi.KERNEL_FILTER_REFINE))
+    assert got.n_kept == 4500 and got.argmax_row == int(want.argmax_row)
+    assert abs(got.rare_event - want.rare_event) <= 1e-12 * want.rare_event
+    model.close()
