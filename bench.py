@@ -356,7 +356,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "frac_real": (traffic / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "note": "achieved/frac = SURVEY 8(d) ALGORITHMIC bytes (canonical CSR, 32 B per cut set) / kernel time: an "
-                        "equivalent rate, not bytes moved -- the filter streams a 24.1 B-per-cut-set re-encoding; frac_real = "
+                        "equivalent rate, not bytes moved -- the filter streams a re-encoding of the model (stream_bytes_per_launch: 18.1 B per cut set in the 24-bit form, 24.1 B otherwise), so frac may exceed 1; frac_real = "
                         "PMC-measured HBM bytes / kernel time / peak. Both hold while few rows pass the filter (config.workload); "
                         "see also.cut_off_0 for the all-rows case",
                 "kernel": kernel_label,
