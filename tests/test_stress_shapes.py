@@ -138,3 +138,38 @@ def test_packed_row_sums_do_not_carry_into_the_neighbour(gpu_ctx, oracle, long_l
     assert got.n_kept == 4500 and got.argmax_row == int(want.argmax_row)
     assert abs(got.rare_event - want.rare_event) <= 1e-12 * want.rare_event
     model.close()
+
+
+def test_pipelined_passes_over_alternating_models(gpu_ctx, oracle):
+    """Consecutive asynchronous passes share three lanes of scratch: two models of different sizes and cut-offs in
+    alternation (scratch of a lane regrows between passes, the quantised table is rebuilt per model), fetched at irregular
+    points, must give what each model gives alone."""
+    from canopy_amd import combine_partials, default_params
+    specs = [(600_000, 100_000, 6, 1e-8), (1_300_000, 3_000, 5, 1e-6), (20_000, 500, 4, 1e-8)]
+    models, wants, prms = [], [], []
+    for k, (n_rows, n_events, avg, cut) in enumerate(specs):
+        row_ptr, col = oracle.synth_csr(100 + k, n_rows, n_events, avg, n_threads=4)
+        p = oracle.synth_probabilities(100 + k, n_events)
+        m = gpu_ctx.upload(row_ptr, col, n_events)
+        m.set_probabilities(p)
+        models.append(m)
+        prms.append(default_params(cut_off=cut))
+        wants.append(oracle.quantify(row_ptr, col, p, cut_off=cut, limit_order=20, n_threads=4, want_rows=False))
+    gpu_ctx.set_pipeline(True)
+    rng = np.random.default_rng(5)
+    try:
+        last = None
+        for i in range(120):
+            last = int(rng.integers(0, len(models)))
+            gpu_ctx.quantify_async(models[last], prms[last])
+            if rng.random() < 0.2:
+                got = combine_partials([gpu_ctx.fetch_partial()])
+                w = wants[last]
+                assert got.n_kept == int(w.n_kept) and got.argmax_row == int(w.argmax_row), (i, last)
+                assert abs(got.rare_event - w.rare_event) <= 1e-12 * w.rare_event
+        got = combine_partials([gpu_ctx.fetch_partial()])
+        assert got.n_kept == int(wants[last].n_kept)
+    finally:
+        gpu_ctx.synchronize()
+        for m in models:
+            m.close()
