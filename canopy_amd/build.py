@@ -39,11 +39,19 @@ def _newer(target, deps):
 
 
 def build(force=False, verbose=False):
-    """One object per source (compiled in parallel, only when stale), then one link."""
+    """One object per source (compiled in parallel, only when stale), then one link.
+
+    CANOPY_ABLATIONS=1 in the environment of THIS script compiles the tuning switches and timing ablations of
+    benchmarks/ in (-DCANOPY_ABLATIONS); the default library reads no environment variable at run time."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ_DIR, exist_ok=True)
     common = _deps_common()
     flags = [f for f in FLAGS if f != "-shared"]
+    if os.environ.get("CANOPY_ABLATIONS", "") not in ("", "0"):
+        flags.append("-DCANOPY_ABLATIONS")
+    stamp = os.path.join(OBJ_DIR, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True  # another flag set built the objects that are there
     jobs = []
     objs = []
     for src in SOURCES:
@@ -57,6 +65,8 @@ def build(force=False, verbose=False):
     failed = [src for src, pr in jobs if pr.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
     if force or jobs or _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-ldl", "-o", LIB]
         if verbose:

@@ -178,7 +178,7 @@ canopy_status canopy_ctx_create(const canopy_ctx_params* params, canopy_ctx** ou
             if (st == CANOPY_OK && hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming) != hipSuccess) st = CANOPY_ERR_HIP;
         }
         if (st != CANOPY_OK) break;
-        static const bool no_pipe = getenv("CANOPY_NO_PIPELINE") != nullptr;
+        static const bool no_pipe = CANOPY_TUNE_ENV("CANOPY_NO_PIPELINE") != nullptr;
         ctx->pipeline_on = !no_pipe;
     } while (0);
     if (st != CANOPY_OK) {
@@ -448,7 +448,7 @@ canopy_status build_fr(canopy_ctx* ctx, canopy_model* m) {
         m->device_bytes += (m->fr_total_chunks + 1) * (768 + 4) + (m->n_fr_slabs + 1) * 4;
         // the quantised filter reads the 24-bit form only: the 32-bit stream goes, and comes back (ensure_fr32, ~15 ms at
         // 1e8 rows) for the first pass that reads it -- the fixed-point pass, the gathered fp64 filter
-        static const bool keep32 = getenv("CANOPY_FR_KEEP32") != nullptr; // tuning only
+        static const bool keep32 = CANOPY_TUNE_ENV("CANOPY_FR_KEEP32") != nullptr; // tuning only
         if (!keep32) {
             (void)hipFree(m->d_fr_stream);
             m->d_fr_stream = nullptr;

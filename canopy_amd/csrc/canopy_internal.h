@@ -10,6 +10,16 @@
 #include "canopy.h"
 #include "canopy_guard.h"
 
+// Tuning switches and timing ablations of benchmarks/ (environment variables CANOPY_*): compiled in only with
+// -DCANOPY_ABLATIONS (CANOPY_ABLATIONS=1 python -m canopy_amd.build). The default build reads NO environment variable:
+// some of the ablations give wrong results by design, and a stray variable must never change a quantification.
+#ifdef CANOPY_ABLATIONS
+#include <stdlib.h>
+#define CANOPY_TUNE_ENV(name) getenv(name)
+#else
+#define CANOPY_TUNE_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace canopy {
 struct BatchState; // kernels_batch.hip
 void batch_state_free(BatchState* b);

@@ -130,7 +130,7 @@ canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, ca
     // lane (two cross-queue edges per pass: ~17 us at the shard size of an 8-GPU run). Default: the collective goes straight
     // onto the lane that ran the final reduce; consecutive passes then call RCCL from different streams, which RCCL orders
     // itself (its launches are chained through the communicator's internal device stream).
-    static const bool own_stream = getenv("CANOPY_COMM_OWN_STREAM") != nullptr;
+    static const bool own_stream = CANOPY_TUNE_ENV("CANOPY_COMM_OWN_STREAM") != nullptr;
     if (e == hipSuccess && own_stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int k = 0; k < canopy_ctx::kLanes && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->ev_lane[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_mc, 2 * sizeof(unsigned long long));

@@ -65,7 +65,7 @@ constexpr int kQ8MaxParts = 3;
 constexpr int kFrBucketsC = 512; // column buckets of the builder's counting sort (= kFrBuckets below)
 
 bool fr_q8_allowed() {
-    static const bool off = getenv("CANOPY_FR_NOQ8") != nullptr; // tuning only
+    static const bool off = CANOPY_TUNE_ENV("CANOPY_FR_NOQ8") != nullptr; // tuning only
     return !off;
 }
 bool fr_use_q8(int32_t n_events) { return fr_q8_allowed() && n_events <= kQ8MaxParts * kQ8MaxEvents && n_events <= (1 << 18); }
@@ -85,7 +85,7 @@ int32_t fr_part_first_col(int h, int H, int32_t n_events) {
 }
 
 int fr_slab_rows_for(int32_t n_events) {
-    static const int forced = getenv("CANOPY_FR_SLAB") ? atoi(getenv("CANOPY_FR_SLAB")) : 0; // tuning only
+    static const int forced = CANOPY_TUNE_ENV("CANOPY_FR_SLAB") ? atoi(CANOPY_TUNE_ENV("CANOPY_FR_SLAB")) : 0; // tuning only
     if (forced == 8192 || forced == 16384) return forced;
     if (fr_use_q8(n_events)) return 8192; // quantised LDS-table filter: 8192-row slabs
     return n_events <= (1 << 17) ? 16384 : 8192;
@@ -534,7 +534,13 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint32_t* __r
                                                              const uint8_t* __restrict__ q8, int32_t n_events,
                                                              int64_t n_rows, int64_t n_slabs, int threshold,
                                                              uint16_t* __restrict__ cand_list, unsigned* __restrict__ cand_cnt,
-                                                             unsigned long long* __restrict__ cand_count, int abl) {
+                                                             unsigned long long* __restrict__ cand_count, int abl_arg) {
+#ifdef CANOPY_ABLATIONS
+    const int abl = abl_arg; // CANOPY_FR_DEBUG: timing ablations of benchmarks/ (wrong results)
+#else
+    constexpr int abl = 0;   // the default build has no ablation branch in the loop
+    (void)abl_arg;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* sums = reinterpret_cast<unsigned*>(smem);
     uint8_t* tab = reinterpret_cast<uint8_t*>(smem + kQ8SumsBytes);
@@ -1628,7 +1634,7 @@ __global__ __launch_bounds__(kFx2Waves * kWave) void k_fx2(const uint4* __restri
 // The 24-bit form of an existing 32-bit slab stream (one column part, 8192-row slabs). p->stream stays null (nothing
 // allocated) when more than 1 % of the slabs are exception slabs: the model then keeps the 32-bit form.
 bool fr_p24_applies(int32_t n_events) {
-    static const bool off = getenv("CANOPY_FR_NOP24") != nullptr; // tuning only
+    static const bool off = CANOPY_TUNE_ENV("CANOPY_FR_NOP24") != nullptr; // tuning only
     return !off && fr_use_q8(n_events) && fr_parts_for(n_events) == 1 && fr_slab_rows_for(n_events) == kQ8SlabRows;
 }
 
@@ -1752,7 +1758,7 @@ hipError_t launch_fr_filter_t(const uint32_t* stream, const int64_t* fr_off, int
 hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
                             int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint16_t* cand_list,
                             unsigned* cand_cnt, unsigned long long* cand_count, int n_cu, hipStream_t s) {
-    static const int u = getenv("CANOPY_FR_U") ? atoi(getenv("CANOPY_FR_U")) : 4; // tuning only
+    static const int u = CANOPY_TUNE_ENV("CANOPY_FR_U") ? atoi(CANOPY_TUNE_ENV("CANOPY_FR_U")) : 4; // tuning only
     if (fr_slab_rows_for(n_events) == 16384) {
         if (u == 1) return launch_fr_filter_t<16384, 1>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_list, cand_cnt, cand_count, n_cu, s);
         if (u == 4) return launch_fr_filter_t<16384, 4>(stream, fr_off, total_chunks, logp, n_rows, n_slabs, cand_cut, cand_list, cand_cnt, cand_count, n_cu, s);
@@ -1769,7 +1775,7 @@ hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64
 // it (table_valid), and runs k_fr_filter_q8. q8_buf holds n_events bytes rounded up to 16.
 // overlapped: run k_fr_filter_q8o (fr_q8_overlapped says when it applies)
 bool fr_q8_overlapped(const FrP24* p24, int32_t n_events, int32_t max_row_len) {
-    static const bool off = getenv("CANOPY_FR_NOOVERLAP") != nullptr; // tuning only
+    static const bool off = CANOPY_TUNE_ENV("CANOPY_FR_NOOVERLAP") != nullptr; // tuning only
     return !off && p24 != nullptr && p24->stream != nullptr && max_row_len <= kQ8oMaxRowLen && fr_parts_for(n_events) == 1 &&
            kQ8oSumsBytes + (((size_t)n_events + 15) / 16) * 16 + 2 * kQ8Waves * 4 <= (size_t)160 * 1024;
 }
@@ -1790,8 +1796,8 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    static const int u = getenv("CANOPY_FR_QU") ? atoi(getenv("CANOPY_FR_QU")) : 4; // tuning only (chunks in flight per wave)
-    static const int fr_dbg = getenv("CANOPY_FR_DEBUG") ? atoi(getenv("CANOPY_FR_DEBUG")) : 0; // timing ablations only
+    static const int u = CANOPY_TUNE_ENV("CANOPY_FR_QU") ? atoi(CANOPY_TUNE_ENV("CANOPY_FR_QU")) : 4; // tuning only (chunks in flight per wave)
+    static const int fr_dbg = CANOPY_TUNE_ENV("CANOPY_FR_DEBUG") ? atoi(CANOPY_TUNE_ENV("CANOPY_FR_DEBUG")) : 0; // timing ablations only
     const int H = fr_parts_for(n_events);
     if (H > 1) { // wide event space: one part of the table resident per sweep
         Q8Parts P;
@@ -1815,13 +1821,13 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
                                fr_off, total_chunks, q8_buf, P, n_rows, n_slabs, threshold, cand_list, cand_cnt, cand_count, part_max); \
             return hipGetLastError();                                                                                  \
         } while (0)
-        static const bool no_fold = getenv("CANOPY_FR_NOOVERLAP") != nullptr; // tuning only
+        static const bool no_fold = CANOPY_TUNE_ENV("CANOPY_FR_NOOVERLAP") != nullptr; // tuning only
         const size_t lds_po = kQ8oSumsBytes + part_max + 2 * kQ8Waves * 4;
         const bool folded = !no_fold && max_row_len <= kQ8oMaxRowLen && lds_po <= (size_t)160 * 1024;
         // chunks in flight per wave: a (slab, part) holds total_chunks / (n_slabs * H) chunks on average (97 at E = 2e5); with
         // U = 4 its loop is one full step of 64 chunks and a second, nearly empty one that costs the same latency; U = 6
         // covers it in one step (measured at E = 2e5: 0.6245 -> 0.598 ms; U = 8 0.616)
-        static const bool u_forced = getenv("CANOPY_FR_QU") != nullptr;
+        static const bool u_forced = CANOPY_TUNE_ENV("CANOPY_FR_QU") != nullptr;
         int up = u;
         if (!u_forced) {
             const double avg = n_slabs > 0 ? (double)total_chunks / ((double)n_slabs * H) : 0.0;
@@ -1918,7 +1924,7 @@ hipError_t launch_fx_table(const double* logp, int32_t n_events, uint64_t* fx, h
 
 namespace {
 size_t fx_lds_bytes(int32_t n_events, int slab_rows, bool* tab_lds) {
-    static const bool no_lds = getenv("CANOPY_FX_NOLDS") != nullptr; // tuning only
+    static const bool no_lds = CANOPY_TUNE_ENV("CANOPY_FX_NOLDS") != nullptr; // tuning only
     *tab_lds = !no_lds && (size_t)n_events <= fx_table_lds_max_events(slab_rows);
     return (size_t)(slab_rows + 64) * 8 + (size_t)(slab_rows / 64) * 4 + 16 + (*tab_lds ? (size_t)n_events * 8 : 0);
 }
@@ -1926,7 +1932,7 @@ size_t fx_lds_bytes(int32_t n_events, int slab_rows, bool* tab_lds) {
 
 namespace {
 bool fx_use_overlapped(int32_t n_events) { // k_fx2 needs two 8192-row buffers
-    static const bool old_only = getenv("CANOPY_FX_OLD") != nullptr; // tuning only
+    static const bool old_only = CANOPY_TUNE_ENV("CANOPY_FX_OLD") != nullptr; // tuning only
     return !old_only && fr_slab_rows_for(n_events) == 8192;
 }
 constexpr size_t kFx2FixedLds = (size_t)2 * (kFx2Slab + 64) * 8 + 16 + 64 * 8;
@@ -1947,7 +1953,7 @@ int fx_sum_grid(int n_cu, int32_t n_events, int64_t n_slabs) {
 // rows per candidate-list unit and units per slab of the pass launch_fx_sum will run for this model
 void fx_list_units(int32_t n_events, int* unit_rows, int* units_per_slab) {
     if (fx_use_overlapped(n_events)) {
-        static const int add_env = getenv("CANOPY_FX_ADD") ? atoi(getenv("CANOPY_FX_ADD")) : 0; // tuning only
+        static const int add_env = CANOPY_TUNE_ENV("CANOPY_FX_ADD") ? atoi(CANOPY_TUNE_ENV("CANOPY_FX_ADD")) : 0; // tuning only
         const int fw = add_env == 14 ? 2 : (add_env == 8 ? 8 : 4);
         *unit_rows = kFx2Slab / fw;
         *units_per_slab = fw;
@@ -2000,12 +2006,12 @@ hipError_t launch_fx_sum(const uint32_t* stream, const int64_t* fr_off, int64_t 
         sc.t_keep = lo < -0x1.0p62 ? -kAll : (lo > 0x1.0p62 ? kAll : (long long)lo);
         sc.t_drop = hi < -0x1.0p62 ? -kAll : (hi > 0x1.0p62 ? kAll : (long long)hi);
     }
-    static const int u_env = getenv("CANOPY_FX_U") ? atoi(getenv("CANOPY_FX_U")) : 0;  // tuning only
-    static const int w_env = getenv("CANOPY_FX_W") ? atoi(getenv("CANOPY_FX_W")) : 0;  // tuning only (waves per workgroup)
+    static const int u_env = CANOPY_TUNE_ENV("CANOPY_FX_U") ? atoi(CANOPY_TUNE_ENV("CANOPY_FX_U")) : 0;  // tuning only
+    static const int w_env = CANOPY_TUNE_ENV("CANOPY_FX_W") ? atoi(CANOPY_TUNE_ENV("CANOPY_FX_W")) : 0;  // tuning only (waves per workgroup)
     const int slab_rows = fr_slab_rows_for(n_events);
     if (fx_use_overlapped(n_events)) { // adding and folding waves side by side
-        static const int add_env = getenv("CANOPY_FX_ADD") ? atoi(getenv("CANOPY_FX_ADD")) : 0; // tuning only
-        const bool tl = kFx2FixedLds + (size_t)n_events * 8 + 64 <= (size_t)160 * 1024 && !getenv("CANOPY_FX_NOLDS");
+        static const int add_env = CANOPY_TUNE_ENV("CANOPY_FX_ADD") ? atoi(CANOPY_TUNE_ENV("CANOPY_FX_ADD")) : 0; // tuning only
+        const bool tl = kFx2FixedLds + (size_t)n_events * 8 + 64 <= (size_t)160 * 1024 && !CANOPY_TUNE_ENV("CANOPY_FX_NOLDS");
         const bool allkept = log_cut == -INFINITY && !sc.need_len;
         const size_t lds = kFx2FixedLds + (tl ? (size_t)n_events * 8 : 0);
 #define FX2_GO(AD, UU, TL, AK)                                                                                          \

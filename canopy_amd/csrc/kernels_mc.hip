@@ -26,6 +26,12 @@
 #include "canopy_device.h"
 #include "canopy_internal.h"
 
+#ifdef CANOPY_ABLATIONS // CANOPY_MC_DEBUG: timing ablations of benchmarks/mc_ab.sh (wrong results)
+#define MC_ABL(bit) (a.abl & (bit))
+#else
+#define MC_ABL(bit) 0
+#endif
+
 using namespace canopy;
 
 namespace {
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(McArgs a) {
                         const int j = item / W, wi = item - j * W;
                         ctr = (DAG_LDS ? s_ek[j] : mix64(a.key ^ (uint64_t)j)) + (uint64_t)(a.first_word + w0 + wi) * 64u;
                         T = DAG_LDS ? s_th[j] : a.thresh[j];
-                        const bool certain = (T >> 53) != 0 || (a.abl & 1); // p == 1
+                        const bool certain = (T >> 53) != 0 || MC_ABL(1); // p == 1
                         lt = certain ? ~0ULL : 0ULL;
                         und = certain ? 0ULL : ~0ULL;
                         k = 0;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(McArgs a) {
         }
         __syncthreads();
         // ---- phase 2: gates, level by level, lane per (gate, WL words)
-        for (int lv = 0; lv < ((a.abl & 2) ? 0 : a.n_levels); ++lv) {
+        for (int lv = 0; lv < (MC_ABL(2) ? 0 : a.n_levels); ++lv) {
             const int g0 = a.level_ptr[lv], g1 = a.level_ptr[lv + 1];
             for (int it = tid; it < (g1 - g0) * S; it += kMcThreads) {
                 const int g = g0 + it / S, sub = it % S;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(McArgs a) {
                 const bool vote = type == CANOPY_GATE_ATLEAST, is_xor = type == CANOPY_GATE_XOR;
                 const bool any_vote = __any(vote), any_xor = __any(is_xor);
                 Words<WL> r;
-                const int q_end = (a.abl & 8) ? b : e;
+                const int q_end = MC_ABL(8) ? b : e;
                 if (!any_vote && !any_xor) { // the common wave: OR accumulation only, no branches in the loop
                     uint64_t ro[WL];
 #pragma unroll
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(McArgs a) {
 #pragma unroll
                 for (int i = 0; i < WL; ++i) dst[i] = r.v[i];
             }
-            if (!(a.abl & 4)) __syncthreads();
+            if (!MC_ABL(4)) __syncthreads();
         }
         // ---- top node
         if (tid < W) {
@@ -512,7 +518,7 @@ canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* d, const ca
             for (int w = 16; w >= 2; w >>= 1)
                 if (n_nodes * (size_t)w * 8 <= (size_t)156 * 1024) { W = w; break; }
     }
-    static const int w_env = getenv("CANOPY_MC_W") ? atoi(getenv("CANOPY_MC_W")) : 0; // tuning only
+    static const int w_env = CANOPY_TUNE_ENV("CANOPY_MC_W") ? atoi(CANOPY_TUNE_ENV("CANOPY_MC_W")) : 0; // tuning only
     if (dag_lds && (w_env == 1 || w_env == 2 || w_env == 4 || w_env == 8 || w_env == 16) &&
         n_nodes * (size_t)w_env * 8 + dag_bytes <= (size_t)156 * 1024)
         W = w_env;
@@ -526,10 +532,10 @@ canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* d, const ca
     a.n_words = (prm->num_trials + 63) / 64;
     a.num_trials = prm->num_trials;
     a.hits = ctx->d_mc_hits;
-    static const int mc_dbg = getenv("CANOPY_MC_DEBUG") ? atoi(getenv("CANOPY_MC_DEBUG")) : 0; // tuning only
+    static const int mc_dbg = CANOPY_TUNE_ENV("CANOPY_MC_DEBUG") ? atoi(CANOPY_TUNE_ENV("CANOPY_MC_DEBUG")) : 0; // tuning only
     a.abl = mc_dbg;
     a.vote_planes = d->vote_planes;
-    static const int p1_env = getenv("CANOPY_MC_P1") ? atoi(getenv("CANOPY_MC_P1")) : 0; // tuning only
+    static const int p1_env = CANOPY_TUNE_ENV("CANOPY_MC_P1") ? atoi(CANOPY_TUNE_ENV("CANOPY_MC_P1")) : 0; // tuning only
     a.p1_lanes = (p1_env >= 64 && p1_env <= kMcThreads && p1_env % 64 == 0) ? p1_env : kMcThreads;
     const int64_t n_tiles = (a.n_words + W - 1) / W;
     const int64_t blocks_per_cu = std::max<int64_t>(1, std::min<int64_t>(4, (160 * 1024) / lds)); // 8 waves each

@@ -369,17 +369,22 @@ hipError_t launch_vs_kernel(const RowKernelArgs& ra, const uint32_t* stream, con
     sc.total_chunks = total_chunks;
     sc.n_rows = ra.n_rows; sc.n_slabs = n_slabs; sc.row_offset = ra.row_offset;
     sc.log_cut = ra.log_cut; sc.limit_order = ra.limit_order;
-    static const int dbg = getenv("CANOPY_VS_DEBUG") ? atoi(getenv("CANOPY_VS_DEBUG")) : 0; // timing ablations only
-    { // per device, cheap: every launch
-        const void* fn = dbg == 1 ? reinterpret_cast<const void*>(&k_vs<1>) : dbg == 2 ? reinterpret_cast<const void*>(&k_vs<2>)
-                         : dbg == 3 ? reinterpret_cast<const void*>(&k_vs<3>) : reinterpret_cast<const void*>(&k_vs<0>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-    }
-#define VS_LAUNCH(A) hipLaunchKernelGGL(k_vs<A>, dim3(grid), dim3(kVsThreads), VsLds::total, s, reinterpret_cast<const uint4*>(stream), vs_off, slab_row, ra.row_ptr, ra.logp, sc, ra.block_partials, ra.row_logp_out, ra.keep_mask_out)
-    if (dbg == 1) VS_LAUNCH(1); else if (dbg == 2) VS_LAUNCH(2); else if (dbg == 3) VS_LAUNCH(3); else VS_LAUNCH(0);
+#define VS_LAUNCH(A)                                                                                                   \
+    do { /* (the LDS attribute is per device and cheap to set: every launch) */                                        \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vs<A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (e_ != hipSuccess) return e_;                                                                               \
+        hipLaunchKernelGGL(k_vs<A>, dim3(grid), dim3(kVsThreads), VsLds::total, s, reinterpret_cast<const uint4*>(stream), vs_off, \
+                           slab_row, ra.row_ptr, ra.logp, sc, ra.block_partials, ra.row_logp_out, ra.keep_mask_out);   \
+        return hipGetLastError();                                                                                      \
+    } while (0)
+#ifdef CANOPY_ABLATIONS // timing ablations of benchmarks/ (wrong results)
+    static const int dbg = CANOPY_TUNE_ENV("CANOPY_VS_DEBUG") ? atoi(CANOPY_TUNE_ENV("CANOPY_VS_DEBUG")) : 0;
+    if (dbg == 1) VS_LAUNCH(1);
+    if (dbg == 2) VS_LAUNCH(2);
+    if (dbg == 3) VS_LAUNCH(3);
+#endif
+    VS_LAUNCH(0);
 #undef VS_LAUNCH
-    return hipGetLastError();
 }
 
 } // namespace canopy

@@ -316,11 +316,7 @@ int grid_for(int64_t n, int block) {
 
 } // namespace
 
-int ws_rows_per_wave() {
-    static const int dbg = getenv("CANOPY_WS_DEBUG") ? atoi(getenv("CANOPY_WS_DEBUG")) : 0;
-    (void)dbg;
-    return 4096;
-}
+int ws_rows_per_wave() { return 4096; }
 int ws_max_events() { return 1 << (32 - (ws_rows_per_wave() > 4096 ? 14 : 13)); }
 
 int ws_default_grid(int n_cu, int64_t n_ws) {
@@ -396,7 +392,7 @@ hipError_t ws_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     hipLaunchKernelGGL((k_ws_build<true>), dim3(grid_for(n_ws, 64)), dim3(64), 0, s, d_row_ptr, d_col_idx, n_rows,
                        n_events, rw, rw > 4096 ? 14 : 13, n_ws, gcap, d_cnt, (int64_t*)nullptr, (const int64_t*)d_off, d_stream, d_ovf);
     e = hipGetLastError();
-    static const bool no_sort = getenv("CANOPY_WS_NOSORT") != nullptr; // tuning only
+    static const bool no_sort = CANOPY_TUNE_ENV("CANOPY_WS_NOSORT") != nullptr; // tuning only
     if (e == hipSuccess && total > 0 && !no_sort) {
         hipLaunchKernelGGL(k_ws_sort_groups, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, reinterpret_cast<uint4*>(d_stream), total);
         e = hipGetLastError();
@@ -436,8 +432,8 @@ hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, con
     sc.total_chunks = total_chunks;
     sc.n_rows = ra.n_rows; sc.n_ws = n_ws; sc.row_offset = ra.row_offset;
     sc.log_cut = ra.log_cut; sc.limit_order = ra.limit_order; sc.need_len = need_len;
-    // tuning/ablation switch for benchmarks/ experiments only (timing builds produce wrong results)
-    static const int dbg = getenv("CANOPY_WS_DEBUG") ? atoi(getenv("CANOPY_WS_DEBUG")) : 0;
+#ifdef CANOPY_ABLATIONS // benchmarks/ experiments only (the timing ablations produce wrong results)
+    static const int dbg = CANOPY_TUNE_ENV("CANOPY_WS_DEBUG") ? atoi(CANOPY_TUNE_ENV("CANOPY_WS_DEBUG")) : 0;
     switch (dbg) {
         case 1: return launch_ws_t<4096, 8, 1>(ra, stream, ws_off, sc, grid, s); // no gathers
         case 2: return launch_ws_t<4096, 8, 2>(ra, stream, ws_off, sc, grid, s); // no LDS adds
@@ -446,8 +442,10 @@ hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, con
         case 10: return launch_ws_t<4096, 10, 0>(ra, stream, ws_off, sc, grid, s);
         case 12: return launch_ws_t<4096, 12, 0>(ra, stream, ws_off, sc, grid, s);
         case 6: return launch_ws_t<4096, 6, 0>(ra, stream, ws_off, sc, grid, s);
-        default: return launch_ws_t<4096, 8, 0>(ra, stream, ws_off, sc, grid, s);
+        default: break;
     }
+#endif
+    return launch_ws_t<4096, 8, 0>(ra, stream, ws_off, sc, grid, s);
 }
 
 } // namespace canopy
