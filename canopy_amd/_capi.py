@@ -31,6 +31,7 @@ APPROX_RARE_EVENT, APPROX_MCUB, APPROX_BOTH = 1, 2, 3
 QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK, QUANT_IMPORTANCE = 1, 2, 4, 8
 BATCH_LOG_INPUT = 1
 GATE_AND, GATE_OR, GATE_ATLEAST, GATE_XOR, GATE_NOT, GATE_NAND, GATE_NOR, GATE_NULL = range(8)
+COMM_CHAINED, COMM_UNORDERED, COMM_OWN_STREAM = 0, 1, 2
 KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER, KERNEL_FILTER_REFINE, KERNEL_FIXED_SUM = range(7)
 
 
@@ -71,7 +72,8 @@ class DagView(C.Structure):
 
 
 class McParams(C.Structure):
-    _fields_ = [("seed", C.c_uint64), ("first_sample", C.c_int64), ("num_trials", C.c_int64)]
+    _fields_ = [("seed", C.c_uint64), ("first_sample", C.c_int64), ("num_trials", C.c_int64),
+                ("batch_size", C.c_int32), ("sample_size", C.c_int32)]
 
 
 class McResult(C.Structure):
@@ -109,10 +111,14 @@ SIGNATURES = {
     "canopy_model_get_info": (C.c_int, [C.c_void_p, C.POINTER(ModelInfo)]),
     "canopy_model_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "canopy_model_set_probabilities": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "canopy_model_set_log_probabilities": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "canopy_model_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "canopy_quant_params_default": (None, [C.POINTER(QuantParams)]),
     "canopy_quantify_async": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QuantParams)]),
     "canopy_quantify_fetch": (C.c_int, [C.c_void_p, C.POINTER(Partial)]),
+    "canopy_quantify_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QuantParams), C.POINTER(C.c_uint64)]),
+    "canopy_ticket_fetch": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(Partial)]),
+    "canopy_ticket_done": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int32)]),
     "canopy_quantify": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QuantParams), C.POINTER(QuantResult)]),
     "canopy_ctx_partials_device": (C.c_void_p, [C.c_void_p]),
     "canopy_ctx_set_gather_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
@@ -124,6 +130,8 @@ SIGNATURES = {
     "canopy_comm_quantify_all_async": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
                                                  C.POINTER(QuantParams)]),
     "canopy_comm_fetch": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(QuantResult), C.POINTER(Partial)]),
+    "canopy_comm_ticket_fetch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(QuantResult), C.POINTER(Partial)]),
+    "canopy_comm_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "canopy_comm_last_collective_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "canopy_comm_mc_fetch": (C.c_int, [C.c_void_p, C.POINTER(McResult)]),
     "canopy_synthetic_shard_bounds": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
@@ -143,6 +151,7 @@ SIGNATURES = {
     "canopy_dag_upload": (C.c_int, [C.c_void_p, C.POINTER(DagView), C.POINTER(C.c_void_p)]),
     "canopy_dag_free": (None, [C.c_void_p]),
     "canopy_dag_set_probabilities": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "canopy_mc_params_default": (None, [C.POINTER(McParams)]),
     "canopy_mc_run_async": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(McParams)]),
     "canopy_mc_fetch": (C.c_int, [C.c_void_p, C.POINTER(McResult)]),
     "canopy_mc_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(McParams), C.POINTER(McResult)]),

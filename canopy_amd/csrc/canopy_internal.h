@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,11 +25,42 @@
 namespace canopy {
 struct BatchState; // kernels_batch.hip
 void batch_state_free(BatchState* b);
+
+// One VERSION of a model's probabilities on the device, with the tables derived from it. A model keeps a ring of kPSets
+// of them: canopy_model_set_probabilities writes the NEXT set (asynchronously, from a pinned staging buffer) while
+// passes still in flight keep reading the sets they were enqueued with -- a new probability vector does not drain the
+// lanes of a context. Writes into a set (the upload, a table build) are followed by a record of ev_write on the stream
+// they were enqueued on; a pass on any other stream waits for that record once (PassScratch::seen_write).
+constexpr int kPSets = 4;
+struct PSet {
+    double* d_logp = nullptr;     // [n_events]
+    uint8_t* d_q8 = nullptr;      // [n_events rounded up to 16] + 16: quantised -logp of the conservative filter
+    uint64_t* d_fx = nullptr;     // [n_events] fixed-point -logp * 2^47 of the FIXED_SUM pass
+    double* h_stage = nullptr;    // pinned [n_events]: what the upload copies from
+    uint64_t version = 0;         // canopy_model::logp_version of the values in d_logp (0 = never written)
+    bool q8_valid = false, fx_valid = false;
+    double q8_log_cut = 0.0;      // the log cut-off d_q8 was built for
+    hipEvent_t ev_write = nullptr;     // behind the last write into the set (null: an external set, written on the context's stream)
+    hipStream_t write_stream = nullptr;// the stream that write went to (passes on it are ordered by the stream itself)
+    uint64_t write_id = 0;             // canopy_model::write_counter at that write
+    uint64_t reader_ctx = 0;      // id of the context whose passes read the set (0 none, ~0: more than one context)
+    uint64_t read_hi = 0;         // highest pass number (canopy_ctx::seq) of that context that read it
+    bool external = false;        // buffers owned by somebody else (the envelope of a batch)
+};
+constexpr uint64_t kManyReaders = ~0ULL;
+
+// host_pool.cpp: persistent worker threads for the host-side log of the probabilities (glibc log IS the canonical logp).
+// fn(lo, hi) is called on disjoint ranges covering [0, n); returns when all of them have run.
+void host_parallel_for(int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& fn);
+// out[i] = log(p[i]) (is_log: out[i] = p[i]); returns the index of the first value outside [0, 1] (is_log: above 0 or NaN), -1 if none
+int64_t host_log_values(const double* p, double* out, int64_t n, bool is_log);
 } // namespace canopy
 
 struct canopy_comm;
 
 struct canopy_ctx {
+    uint64_t id = 0; // unique per process (never reused): probability sets remember their readers by it
+    uint64_t seq = 0; // pass counter of this context = the ticket of the last enqueued pass
     int device = 0;
     canopy_comm* comm = nullptr; // K5 inside the library (comm_rccl.hip); owned by the caller, detached by canopy_comm_free
     hipStream_t stream = nullptr;
@@ -56,9 +89,24 @@ struct canopy_ctx {
         unsigned long long* d_fr_count = nullptr; // [2]: candidate accumulator of the running pass, total of the finished one
         double* d_partial = nullptr;        // the shard record this lane's final reduce writes (lane 0: ctx->d_partial)
         double* d_gather = nullptr;         // this lane's all-reduce slot buffer when a communicator is attached
-        hipEvent_t ev_done = nullptr;       // end of the lane's last pass
+        hipEvent_t ev_done = nullptr;       // end of the lane's last pass that recorded one
         bool pending = false;               // work on this lane the context's stream has not been ordered behind yet
         bool used = false;
+        // tickets: the record of the lane's last ticketed pass lands in pinned host memory (k_finalize writes it)
+        double* h_rec = nullptr;            // pinned [16]: the shard record [0..8), the filter's candidate total as u64 at [8]
+        uint64_t ticket = 0;                // pass number whose record h_rec (and the communicator's h_lane) will hold; 0 none
+        uint64_t last_seq = 0;              // pass number of the lane's last pass
+        uint64_t pending_lo = 0;            // lowest pass number on this lane not known to have finished (0 = none)
+        bool last_has_event = false;        // ev_done was recorded behind the lane's last pass
+        // probability sets this lane is already ordered behind (model id, write ids per set)
+        uint64_t seen_model = 0;
+        uint64_t seen_write[canopy::kPSets] = {0, 0, 0, 0};
+        // AUTO's feedback (how many rows the conservative pass listed) belongs to the lane that ran the pass
+        uint64_t fb_model = 0;              // model id of the lane's last two-step pass (0 = none / consumed)
+        int64_t fb_rows = 0;
+        double fb_cut_off = -1.0;
+        uint64_t fb_version = 0;
+        int32_t fb_variant = 0;
     } sets[kLanes];
     bool pipeline_on = true;      // canopy_ctx_set_pipeline / CANOPY_NO_PIPELINE
     int pipe_next = 0;            // lane of the next pipelined pass
@@ -81,8 +129,8 @@ struct canopy_ctx {
     hipEvent_t ev_last[3] = {nullptr, nullptr, nullptr};
     bool last_timed = false;
     bool want_last_timing = false; // set around the pass of the synchronous canopy_quantify
-    // batched quantification: "run only the filter of a FILTER_REFINE pass and leave its candidate lists in set 0"
-    bool filter_only_request = false, filter_only_done = false;
+    // batched quantification ("run only the filter of a FILTER_REFINE pass and leave its candidate lists in lane 0"): what that pass left
+    bool filter_only_done = false;
     int filter_only_slab_rows = 0;
     int64_t filter_only_slabs = 0;
     // timing region
@@ -93,14 +141,12 @@ struct canopy_ctx {
     // FILTER_REFINE: candidates flagged by the last filter pass (device counter, pinned mirror)
     int32_t last_variant = 0;                 // CANOPY_KERNEL_* the last quantify pass ran
     unsigned long long* h_fr_count = nullptr;
-    uint64_t fr_pending_id = 0;   // model id whose filter count is still on the device (0 = none)
-    int64_t fr_pending_rows = 0;
     uint64_t fr_known_id = 0;     // last model id with a known candidate fraction
     double fr_known_fraction = -1.0;
     int64_t fr_known_count = 0, fr_known_rows = 0;
-    double fr_known_cut_off = -1.0, fr_pending_cut_off = -1.0; // the feedback applies to the same (model, p, cut-off) only
-    uint64_t fr_known_version = 0, fr_pending_version = 0;
-    int32_t fr_pending_variant = 0, fr_known_variant = 0; // FILTER_REFINE or FIXED_SUM: whose list the count belongs to
+    double fr_known_cut_off = -1.0; // the feedback applies to the same (model, p, cut-off) only
+    uint64_t fr_known_version = 0;
+    int32_t fr_known_variant = 0; // FILTER_REFINE or FIXED_SUM: whose list the count belongs to
     // the same feedback for FIXED_SUM (rows it had to leave to the exact pass), kept apart from the filter's
     uint64_t fx_known_id = 0, fx_known_version = 0;
     double fx_known_fraction = -1.0, fx_known_cut_off = -1.0;
@@ -124,16 +170,26 @@ struct canopy_comm {
     int world = 1, rank = 0;
     double* d_buf = nullptr; // [lanes][world][8] gather slots = the all-reduce buffers, one per lane of the context
     double* h_buf = nullptr; // pinned mirror
-    // CANOPY_COMM_OWN_STREAM=1 only: every collective is enqueued on `stream`, behind an event of the lane whose final
-    // reduce filled the buffer (default: null, the collective rides the lane; RCCL orders calls from different streams)
+    double* h_lane[canopy_ctx::kLanes] = {nullptr, nullptr, nullptr}; // pinned [world][8]: the combined records of a lane's last ticketed pass
+    // Ordering of consecutive collectives (canopy_comm_set_mode). CHAINED (default): the collective rides the lane that
+    // ran the final reduce, behind an event recorded after the PREVIOUS collective of this communicator -- the device
+    // runs the collectives of one communicator strictly in issue order whatever stream they are on. UNORDERED: no such
+    // edge (RCCL chains a communicator's launches itself). OWN_STREAM: every collective on `stream`, behind an event of
+    // the lane whose final reduce filled the buffer.
+    int32_t mode = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_lane[canopy_ctx::kLanes] = {nullptr, nullptr, nullptr}; // "this lane's record is in its slot buffer"
+    hipEvent_t ev_chain[2] = {nullptr, nullptr}; // behind the last collective, alternating (CHAINED)
+    int chain_next = 0;
+    hipStream_t chain_stream = nullptr; // the stream the last collective went to
+    bool chain_valid = false;
     hipEvent_t ev_fin = nullptr, ev_done = nullptr; // around the last all-reduce (timing)
     bool issued = false;
     bool timed_valid = false; // ev_fin / ev_done bracket the last collective
     double* last_buf = nullptr; // slot buffer of the last issued collective
     unsigned long long* d_mc = nullptr; // [2] {hits, trials} of the Monte-Carlo combine
     unsigned long long* h_mc = nullptr;
+    hipStream_t mc_stream = nullptr; // the stream the last Monte-Carlo combine went to
     bool mc_valid = false;
     bool deferred = false;   // one process, N devices: the collectives of a pass are issued together, grouped
 };
@@ -143,7 +199,7 @@ struct canopy_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t model_id = 0;
-    canopy_model* model = nullptr; // must outlive the graph (canopy.h)
+    const canopy_model* model = nullptr; // must outlive the graph (canopy.h)
     uint64_t scratch_gen = 0;      // canopy_ctx::scratch_gen at capture
     int32_t variant = 0;
     bool has_row_logp = false, has_mask = false, has_importance = false;
@@ -166,6 +222,9 @@ struct FrP24Owned { // device buffers of the 24-bit stream form, owned by the mo
     int64_t n_exception_slabs = 0;
 };
 
+// Constness: the C ABI hands quantification a `const canopy_model*` -- the CSR and the probabilities a pass reads are not
+// changed by it. What a pass MAY do is build, once, a derived layout or a derived table it finds missing: those members are
+// `mutable` and every such build runs under `mu`, so several contexts (and host threads) may quantify one model.
 struct canopy_model {
     uint64_t id = 0; // unique per process (never reused): contexts refer to models by id, not by pointer
     int device = 0;
@@ -173,32 +232,31 @@ struct canopy_model {
     int32_t n_events = 0, max_row_len = 0;
     int64_t* d_row_ptr = nullptr; // [n_rows+1], rebased to 0
     int32_t* d_col_idx = nullptr; // [nnz] (+ 16 B of slack for 16-byte slab loads)
-    double* d_logp = nullptr;     // [n_events]
-    uint8_t* d_q8 = nullptr;      // [n_events rounded up to 16] quantised -logp of the FILTER_REFINE filter pass
-    uint64_t logp_version = 0;    // bumped whenever d_logp's contents (or the pointer) change
-    uint64_t* d_fx = nullptr;     // [n_events] fixed-point -logp * 2^47 of the FIXED_SUM pass
-    uint64_t fx_version = 0;      // logp_version d_fx was built from (0 = none)
-    uint64_t q8_version = 0;      // logp_version the table in d_q8 was built from (0 = none)
-    double q8_log_cut = 0.0;      // ... and the log cut-off it was built for
+    mutable std::mutex mu;        // lazy builds of derived layouts / derived tables, the bookkeeping of the sets
+    mutable canopy::PSet psets[canopy::kPSets];
+    int cur = -1;                 // the set canopy_model_set_probabilities wrote last (-1: none yet)
+    uint64_t logp_version = 0;    // bumped by every set_probabilities
+    mutable uint64_t write_counter = 0;
+    mutable int graph_refs = 0;   // captured passes hold the CURRENT set's pointers: while any exists, set_probabilities writes in place
     bool has_p = false;
-    int64_t device_bytes = 0;
+    mutable int64_t device_bytes = 0;
     // derived wave-slab stream layout (kernels_ws.hip), built by canopy_model_prepare
-    uint32_t* d_ws_stream = nullptr;
-    int64_t* d_ws_off = nullptr;
-    int64_t ws_total_chunks = 0, n_ws = 0;
-    int ws_state = 0; // 0 not built, 1 ready, -1 not representable (fall back to ROWS)
+    mutable uint32_t* d_ws_stream = nullptr;
+    mutable int64_t* d_ws_off = nullptr;
+    mutable int64_t ws_total_chunks = 0, n_ws = 0;
+    mutable int ws_state = 0; // 0 not built, 1 ready, -1 not representable (fall back to ROWS)
     // derived value-scatter layout (kernels_vs.hip)
-    uint32_t* d_vs_stream = nullptr;
-    int64_t* d_vs_off = nullptr;
-    int64_t* d_vs_slab_row = nullptr;
-    int64_t vs_total_chunks = 0, n_slabs = 0;
-    int vs_state = 0;
+    mutable uint32_t* d_vs_stream = nullptr;
+    mutable int64_t* d_vs_off = nullptr;
+    mutable int64_t* d_vs_slab_row = nullptr;
+    mutable int64_t vs_total_chunks = 0, n_slabs = 0;
+    mutable int vs_state = 0;
     // derived filter/refine slab stream (kernels_fr.hip)
-    uint32_t* d_fr_stream = nullptr;
-    int64_t* d_fr_off = nullptr;
-    int64_t fr_total_chunks = 0, n_fr_slabs = 0;
-    FrP24Owned fr24; // 24-bit form of the same chunks (quantised filter), or nulls
-    int fr_state = 0;
+    mutable uint32_t* d_fr_stream = nullptr;
+    mutable int64_t* d_fr_off = nullptr;
+    mutable int64_t fr_total_chunks = 0, n_fr_slabs = 0;
+    mutable FrP24Owned fr24; // 24-bit form of the same chunks (quantised filter), or nulls
+    mutable int fr_state = 0;
 };
 
 namespace canopy {
@@ -223,8 +281,11 @@ size_t rows_lds_table_limit_events();
 hipError_t launch_rows_kernel(int variant, const RowKernelArgs& a, int grid, hipStream_t s);
 // fr_count: null, or the FILTER_REFINE candidate counter pair -- [0] (accumulated by the filter) is handed
 // over to [1] (read by the host) and cleared for the next pass
+// host_rec: null, or the lane's pinned record (ticketed passes): the shard record and the candidate total land there too
 hipError_t launch_finalize(const double* block_partials, int n_blocks, double* out, double* gather,
-                           int world, int rank, unsigned long long* fr_count, hipStream_t s);
+                           int world, int rank, unsigned long long* fr_count, double* host_rec, hipStream_t s);
+// copies n doubles from a device buffer into pinned host memory (the combined records behind the all-reduce of a ticketed pass)
+hipError_t launch_publish(const double* src, int n, double* host_dst, hipStream_t s);
 
 // kernels_build.hip
 hipError_t launch_importance(const uint64_t* keep_mask, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx,
@@ -241,9 +302,32 @@ hipError_t synth_build_csr(uint64_t seed, int64_t first_row, int64_t n_rows, int
                            int64_t* nnz_out, hipStream_t s);
 
 
+// quantify_pass.cpp -- the one pass of the path: policy, scratch, launches
+struct PassOptions {
+    bool filter_only = false;       // batch path: run only the conservative filter of FILTER_REFINE, leave its lists in lane 0
+    uint64_t* ticket_out = nullptr; // non-null: the pass is ticketed (its record lands in pinned host memory)
+};
+canopy_status enqueue_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, const canopy_quant_params* params, const PassOptions& opt);
+// makes lane stream `lane` (scratch S) ordered behind the last write into set `slot` of m
+hipError_t order_behind_set(canopy_ctx::PassScratch& S, hipStream_t lane, const canopy_model* m, int slot);
+// blocks the host until no pass of ctx (or anybody's, if the readers are unknown) still reads P
+hipError_t wait_set_readers(canopy_ctx* ctx, PSet& P);
+// consumes the AUTO feedback of lane S given the candidate total its last two-step pass published
+void apply_feedback(canopy_ctx* ctx, canopy_ctx::PassScratch& S, unsigned long long count);
+// lazy derived layouts (under m->mu)
+canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m);
+canopy_status ensure_fr32(canopy_ctx* ctx, const canopy_model* m);
+canopy_status build_vs(canopy_ctx* ctx, const canopy_model* m);
+canopy_status build_ws(canopy_ctx* ctx, const canopy_model* m);
+int auto_variant(const canopy_model* m);
+int64_t fr_min_rows(int base_variant);
+canopy_status fail(canopy_ctx* ctx, canopy_status st, const std::string& msg);
+uint64_t next_object_id();
+
 // comm_rccl.hip
-// the single collective of a pass, enqueued on the stream its final reduce ran on
-canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane, bool timed);
+// the single collective of a pass, enqueued on the stream its final reduce ran on; publish: also copy the combined
+// records into the lane's pinned buffer (ticketed pass)
+canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane, bool timed, bool publish);
 hipStream_t comm_stream(canopy_ctx* ctx);
 // orders the context's stream behind everything enqueued on the other lanes (device-side waits, no host blocking)
 hipError_t ctx_join_side(canopy_ctx* ctx);
@@ -295,6 +379,7 @@ struct FrP24 {
 bool fr_p24_applies(int32_t n_events);
 hipError_t fr_build_pack24(const uint32_t* d_stream32, const int64_t* d_fr_off, int64_t n_slabs, int64_t total_chunks, int32_t n_events,
                            FrP24Owned* p, hipStream_t s);
+hipError_t launch_fr_q8_table(const double* logp, int32_t n_events, double log_cut, uint8_t* q8_buf, hipStream_t s);
 bool fr_q8_overlapped(const FrP24* p24, int32_t n_events, int32_t max_row_len);
 void fr_q8_overlapped_units(int* unit_rows, int* units_per_slab);
 hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool overlapped, int32_t max_row_len, const int64_t* fr_off,

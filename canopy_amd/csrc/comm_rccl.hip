@@ -105,6 +105,8 @@ void comm_release(canopy_comm* c) { // device / host resources only (not the RCC
     if (c->h_buf) (void)hipHostFree(c->h_buf);
     if (c->d_mc) (void)hipFree(c->d_mc);
     if (c->h_mc) (void)hipHostFree(c->h_mc);
+    for (auto h : c->h_lane) if (h) (void)hipHostFree(h);
+    for (auto e : c->ev_chain) if (e) (void)hipEventDestroy(e);
     if (c->ev_fin) (void)hipEventDestroy(c->ev_fin);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     for (auto e : c->ev_lane) if (e) (void)hipEventDestroy(e);
@@ -126,13 +128,12 @@ canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, ca
     if (e == hipSuccess) e = hipHostMalloc(&c->h_buf, bytes);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_fin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_done);
-    // CANOPY_COMM_OWN_STREAM=1: every collective on ONE stream of the communicator's own, behind an event of the pass's
-    // lane (two cross-queue edges per pass: ~17 us at the shard size of an 8-GPU run). Default: the collective goes straight
-    // onto the lane that ran the final reduce; consecutive passes then call RCCL from different streams, which RCCL orders
-    // itself (its launches are chained through the communicator's internal device stream).
-    static const bool own_stream = CANOPY_TUNE_ENV("CANOPY_COMM_OWN_STREAM") != nullptr;
-    if (e == hipSuccess && own_stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // Default mode CANOPY_COMM_CHAINED: the collective goes onto the lane that ran the final reduce, behind an event
+    // recorded after the communicator's previous collective (canopy_comm_set_mode has the alternatives).
+    c->mode = CANOPY_COMM_CHAINED;
     for (int k = 0; k < canopy_ctx::kLanes && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->ev_lane[k], hipEventDisableTiming);
+    for (int k = 0; k < canopy_ctx::kLanes && e == hipSuccess; ++k) e = hipHostMalloc(&c->h_lane[k], bytes);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->ev_chain[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_mc, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_mc, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_buf, 0, canopy_ctx::kLanes * bytes, ctx->stream);
@@ -154,30 +155,45 @@ canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, ca
 
 namespace canopy {
 
-// Called by canopy_quantify_async right behind k_finalize: buf = the slot buffer of the pass's lane, lane_stream = the
-// stream its final reduce ran on. No host round trip.
-canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane, bool timed) {
+// Called by the pass right behind k_finalize: buf = the slot buffer of the pass's lane, lane_stream = the stream its
+// final reduce ran on. No host round trip. Consecutive passes of a pipelined sequence run on different lanes, i.e. issue
+// the collectives of ONE communicator from different streams; in the default CHAINED mode each collective waits (device
+// side) for an event recorded behind the previous one, so the device runs them strictly in issue order -- the same
+// order on every rank -- without relying on what RCCL does between streams. The edge sits in the lane's latency-bound
+// tail, not in front of the next pass's row kernel.
+canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane, bool timed, bool publish) {
     canopy_comm* c = ctx->comm;
     if (!c || c->deferred) return CANOPY_OK;
     hipStream_t st = lane_stream;
-    if (c->stream) { // own-stream mode
+    if (c->mode == CANOPY_COMM_OWN_STREAM && c->stream) {
         HIPC_TRY(ctx, hipEventRecord(c->ev_lane[lane], lane_stream));
         HIPC_TRY(ctx, hipStreamWaitEvent(c->stream, c->ev_lane[lane], 0));
         st = c->stream;
+    } else if (c->mode == CANOPY_COMM_CHAINED && c->chain_valid && c->chain_stream != st) {
+        HIPC_TRY(ctx, hipStreamWaitEvent(st, c->ev_chain[c->chain_next ^ 1], 0)); // behind the previous collective
     }
     // the two events around the collective only for a timed pass (an event record is a packet on the stream and a few
     // microseconds of host time: not on the path of every pass of an 8-way shard)
     if (timed) HIPC_TRY(ctx, hipEventRecord(c->ev_fin, st));
     RCCL_TRY(ctx, rccl()->AllReduce(buf, buf, (size_t)c->world * CANOPY_PARTIAL_DOUBLES, ncclDouble, ncclSum,
                                     static_cast<ncclComm_t>(c->comm), st));
-    if (timed || c->stream) HIPC_TRY(ctx, hipEventRecord(c->ev_done, st));
+    if (c->mode == CANOPY_COMM_CHAINED) {
+        HIPC_TRY(ctx, hipEventRecord(c->ev_chain[c->chain_next], st));
+        c->chain_next ^= 1;
+        c->chain_stream = st;
+        c->chain_valid = true;
+    }
+    if (publish) HIPC_TRY(ctx, canopy::launch_publish(buf, c->world * CANOPY_PARTIAL_DOUBLES, c->h_lane[lane], st));
+    if (timed || st != lane_stream) HIPC_TRY(ctx, hipEventRecord(c->ev_done, st));
     c->timed_valid = timed;
     c->issued = true;
     c->last_buf = buf;
     return CANOPY_OK;
 }
 
-hipStream_t comm_stream(canopy_ctx* ctx) { return (ctx->comm && !ctx->comm->deferred) ? ctx->comm->stream : nullptr; } // null: collectives ride the lanes
+hipStream_t comm_stream(canopy_ctx* ctx) { // null: collectives ride the lanes
+    return (ctx->comm && !ctx->comm->deferred && ctx->comm->mode == CANOPY_COMM_OWN_STREAM) ? ctx->comm->stream : nullptr;
+}
 
 // K6: [hits, trials] of every rank summed (one u64 all-reduce of 2 words), same stream.
 canopy_status comm_all_reduce_mc(canopy_ctx* ctx, const unsigned long long* d_hits, long long trials) {
@@ -186,12 +202,21 @@ canopy_status comm_all_reduce_mc(canopy_ctx* ctx, const unsigned long long* d_hi
     hipLaunchKernelGGL(k_mc_pack, dim3(1), dim3(1), 0, ctx->stream, c->d_mc, d_hits, (unsigned long long)trials);
     HIPC_TRY(ctx, hipGetLastError());
     hipStream_t st = ctx->stream;
-    if (c->stream) {
+    if (c->mode == CANOPY_COMM_OWN_STREAM && c->stream) {
         HIPC_TRY(ctx, hipEventRecord(c->ev_lane[0], ctx->stream)); // the communicator's own stream, behind the pack
         HIPC_TRY(ctx, hipStreamWaitEvent(c->stream, c->ev_lane[0], 0));
         st = c->stream;
+    } else if (c->mode == CANOPY_COMM_CHAINED && c->chain_valid && c->chain_stream != st) {
+        HIPC_TRY(ctx, hipStreamWaitEvent(st, c->ev_chain[c->chain_next ^ 1], 0));
     }
     RCCL_TRY(ctx, rccl()->AllReduce(c->d_mc, c->d_mc, 2, ncclUint64, ncclSum, static_cast<ncclComm_t>(c->comm), st));
+    if (c->mode == CANOPY_COMM_CHAINED) {
+        HIPC_TRY(ctx, hipEventRecord(c->ev_chain[c->chain_next], st));
+        c->chain_next ^= 1;
+        c->chain_stream = st;
+        c->chain_valid = true;
+    }
+    c->mc_stream = st;
     c->mc_valid = true;
     return CANOPY_OK;
 }
@@ -261,15 +286,16 @@ canopy_status canopy_comm_init_all(canopy_ctx* const* ctxs, int32_t n, canopy_co
 void canopy_comm_free(canopy_comm* c) {
     if (!c) return;
     canopy_ctx* ctx = c->ctx;
-    if (ctx) {
+    if (ctx) { // (null once its context has been freed: canopy_ctx_free takes a forgotten communicator with it)
         (void)hipSetDevice(ctx->device);
         (void)canopy::ctx_join_side(ctx);
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         if (ctx->comm == c) {
             ctx->comm = nullptr;
             (void)canopy_ctx_set_gather_buffer(ctx, nullptr, 0, 0);
-            for (auto& S : ctx->sets) S.d_gather = nullptr;
+            for (auto& S : ctx->sets) { S.d_gather = nullptr; S.ticket = 0; }
         }
+        c->ctx = nullptr;
     }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl()->handle) (void)rccl()->CommDestroy(static_cast<ncclComm_t>(c->comm));
@@ -308,6 +334,11 @@ canopy_status canopy_comm_quantify_all_async(canopy_comm* const* comms, const ca
         canopy_comm* c = comms[i];
         c->issued = true;
         c->last_buf = c->d_buf;
+        if (hipSetDevice(c->ctx->device) != hipSuccess) { // each grouped call on its own device
+            (void)hipGetLastError();
+            (void)api->GroupEnd();
+            return comm_fail(c->ctx, CANOPY_ERR_HIP, "hipSetDevice failed inside the grouped all-reduce");
+        }
         ncclResult_t r = api->AllReduce(c->d_buf, c->d_buf, (size_t)c->world * CANOPY_PARTIAL_DOUBLES, ncclDouble, ncclSum,
                                         static_cast<ncclComm_t>(c->comm), c->ctx->stream);
         if (r != ncclSuccess) {
@@ -335,6 +366,46 @@ canopy_status canopy_comm_fetch(canopy_comm* c, uint32_t flags, canopy_quant_res
     return CANOPY_OK;
 } CANOPY_CATCH_ALL
 
+canopy_status canopy_comm_set_mode(canopy_comm* c, int32_t mode) try {
+    if (!c || !c->ctx) return CANOPY_ERR_INVALID_ARGUMENT;
+    if (mode != CANOPY_COMM_CHAINED && mode != CANOPY_COMM_UNORDERED && mode != CANOPY_COMM_OWN_STREAM)
+        return comm_fail(c->ctx, CANOPY_ERR_INVALID_ARGUMENT, "unknown communicator mode");
+    canopy_ctx* ctx = c->ctx;
+    HIPC_TRY(ctx, hipSetDevice(ctx->device));
+    // nothing in flight while the discipline changes
+    HIPC_TRY(ctx, canopy::ctx_join_side(ctx));
+    HIPC_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (c->stream) HIPC_TRY(ctx, hipStreamSynchronize(c->stream));
+    if (mode == CANOPY_COMM_OWN_STREAM && !c->stream) HIPC_TRY(ctx, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->mode = mode;
+    c->chain_valid = false;
+    return CANOPY_OK;
+} CANOPY_CATCH_ALL
+
+// The combined records of a ticketed pass: its lane published them into pinned host memory right behind the all-reduce;
+// this waits for THAT lane only and folds them in rank order.
+canopy_status canopy_comm_ticket_fetch(canopy_comm* c, canopy_ticket ticket, uint32_t flags, canopy_quant_result* result,
+                                       canopy_partial* parts) try {
+    if (!c || !c->ctx || ticket == 0 || (!result && !parts)) return CANOPY_ERR_INVALID_ARGUMENT;
+    canopy_ctx* ctx = c->ctx;
+    if (c->deferred) return comm_fail(ctx, CANOPY_ERR_UNSUPPORTED, "tickets belong to the process-per-GPU shape (canopy_comm_init_rank)");
+    for (int k = 0; k < canopy_ctx::kLanes; ++k) {
+        canopy_ctx::PassScratch& S = ctx->sets[k];
+        if (S.ticket != ticket) continue;
+        HIPC_TRY(ctx, hipSetDevice(ctx->device));
+        HIPC_TRY(ctx, hipEventSynchronize(S.ev_done));
+        if (S.last_seq == ticket) S.pending_lo = 0;
+        unsigned long long count = 0;
+        memcpy(&count, S.h_rec + CANOPY_PARTIAL_DOUBLES, sizeof(count));
+        canopy::apply_feedback(ctx, S, count);
+        const canopy_partial* recs = reinterpret_cast<const canopy_partial*>(c->h_lane[k]);
+        if (parts) memcpy(parts, recs, sizeof(canopy_partial) * (size_t)c->world);
+        if (result) return canopy_combine_partials(recs, c->world, flags, result);
+        return CANOPY_OK;
+    }
+    return comm_fail(ctx, CANOPY_ERR_STATE, "ticket expired or unknown: a lane keeps the records of its LAST ticketed pass only");
+} CANOPY_CATCH_ALL
+
 canopy_status canopy_comm_last_collective_ms(canopy_comm* c, double* ms) try {
     if (!c || !c->ctx || !ms) return CANOPY_ERR_INVALID_ARGUMENT;
     if (!c->issued || c->deferred || !c->timed_valid)
@@ -353,7 +424,7 @@ canopy_status canopy_comm_mc_fetch(canopy_comm* c, canopy_mc_result* r) try {
     if (!c->mc_valid) return comm_fail(ctx, CANOPY_ERR_STATE, "no Monte-Carlo run since the communicator was attached");
     HIPC_TRY(ctx, hipSetDevice(ctx->device));
     unsigned long long host[2];
-    hipStream_t st = c->stream ? c->stream : ctx->stream;
+    hipStream_t st = c->mc_stream ? c->mc_stream : ctx->stream;
     HIPC_TRY(ctx, hipMemcpyAsync(c->h_mc, c->d_mc, sizeof(host), hipMemcpyDeviceToHost, st));
     HIPC_TRY(ctx, hipStreamSynchronize(st));
     host[0] = c->h_mc[0]; host[1] = c->h_mc[1];

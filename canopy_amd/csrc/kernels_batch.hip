@@ -44,6 +44,10 @@ struct BatchState {
     int64_t logpT_cap = 0;
     double* d_logp_max = nullptr;  // [E]
     int64_t max_cap = 0;
+    uint8_t* d_q8 = nullptr;       // [E rounded up to 16] + 16: the quantised filter's table of the envelope
+    int64_t q8_cap = 0;
+    uint64_t* d_fx = nullptr;      // [E] (a fixed-point envelope pass: cut_off 0)
+    int64_t fx_cap = 0;
     int64_t* d_word_off = nullptr; // [n_words] inclusive scan of candidate counts per mask word
     int64_t word_cap = 0;
     int64_t* d_c_row = nullptr;    // [n_c] local row index of candidate i (ascending)
@@ -64,6 +68,9 @@ struct BatchState {
     double* h_out = nullptr;       // pinned mirror
     int64_t h_out_cap = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double* h_stage[2] = {nullptr, nullptr}; // pinned: host logs of one chunk of trials; the copy of one runs while the other is filled
+    int64_t stage_cap = 0;
+    hipEvent_t ev_stage[2] = {nullptr, nullptr}; // behind the device's last read of the staging buffer
     // last batch
     int32_t n_trials = 0;
     double* last_out = nullptr;    // where the records of the last batch live (d_out or the caller's buffer)
@@ -73,10 +80,12 @@ struct BatchState {
 
 void batch_state_free(BatchState* b) {
     if (!b) return;
-    void* ptrs[] = {b->d_in, b->d_logpT, b->d_logp_max, b->d_word_off, b->d_c_row, b->d_c_row_ptr, b->d_c_col, b->d_parts, b->d_out,
+    void* ptrs[] = {b->d_q8, b->d_fx, b->d_in, b->d_logpT, b->d_logp_max, b->d_word_off, b->d_c_row, b->d_c_row_ptr, b->d_c_col, b->d_parts, b->d_out,
                     b->d_slab_kept, b->d_slab_nnz, b->d_totals};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (b->h_out) (void)hipHostFree(b->h_out);
+    for (auto h : b->h_stage) if (h) (void)hipHostFree(h);
+    for (auto e : b->ev_stage) if (e) (void)hipEventDestroy(e);
     if (b->h_totals) (void)hipHostFree(b->h_totals);
     for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
@@ -89,18 +98,13 @@ namespace {
 constexpr int kBatchT = 8;       // trials per lane
 constexpr int kBatchThreads = 256;
 constexpr int kBatchWaves = kBatchThreads / kWave;
-constexpr int kInChunk = 64;     // trials staged per host->device copy
+constexpr int kInChunk = 16;     // trials staged per host->device copy (two pinned staging buffers in rotation)
 
 int grid_for(int64_t n, int block, int64_t cap = (1 << 20)) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
     if (g > cap) g = cap;
     return (int)g;
-}
-
-canopy_status fail(canopy_ctx* ctx, canopy_status st, const std::string& msg) {
-    if (ctx) ctx->last_error = msg;
-    return st;
 }
 
 #define HIP_TRY(ctx, expr)                                                                              \
@@ -416,19 +420,6 @@ __global__ __launch_bounds__(256) void k_finalize_batch(const double* __restrict
     }
 }
 
-void log_rows(const double* p, double* out, int64_t n, bool is_log, int* bad) {
-    for (int64_t i = 0; i < n; ++i) {
-        const double v = p[i];
-        if (is_log) {
-            if (!(v <= 0.0)) *bad = 1; // NaN or a log-probability above 0
-            out[i] = v;
-        } else {
-            if (!(v >= 0.0 && v <= 1.0)) *bad = 1;
-            out[i] = log(v); // glibc log on the host: the canonical logp of canopy_model_set_probabilities
-        }
-    }
-}
-
 } // namespace
 
 extern "C" {
@@ -447,6 +438,7 @@ canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* m, cons
         ctx->batch = new (std::nothrow) BatchState();
         if (!ctx->batch) return CANOPY_ERR_OUT_OF_MEMORY;
         for (auto& e : ctx->batch->ev) HIP_TRY(ctx, hipEventCreate(&e));
+        for (auto& e : ctx->batch->ev_stage) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     BatchState* b = ctx->batch;
     const int32_t E = m->n_events;
@@ -459,31 +451,29 @@ canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* m, cons
     HIP_TRY(ctx, grow(&b->d_in, &b->in_cap, (int64_t)std::min<int32_t>(kInChunk, n_trials) * E));
     {
         const auto t0 = std::chrono::steady_clock::now();
-        std::vector<double> h((size_t)std::min<int32_t>(kInChunk, n_trials) * (size_t)E);
-        unsigned hw = std::thread::hardware_concurrency();
-        const int n_thr = (int)std::max(1u, std::min(hw ? hw : 1u, 32u));
-        for (int32_t c0 = 0; c0 < n_trials; c0 += kInChunk) {
+        const int64_t chunk_doubles = (int64_t)std::min<int32_t>(kInChunk, n_trials) * E;
+        if (b->stage_cap < chunk_doubles) {
+            for (auto& h : b->h_stage) { if (h) (void)hipHostFree(h); h = nullptr; }
+            b->stage_cap = 0;
+            for (auto& h : b->h_stage) HIP_TRY(ctx, hipHostMalloc(&h, sizeof(double) * (size_t)(chunk_doubles > 0 ? chunk_doubles : 1)));
+            b->stage_cap = chunk_doubles;
+        }
+        int turn = 0;
+        for (int32_t c0 = 0; c0 < n_trials; c0 += kInChunk, turn ^= 1) {
             const int32_t nk = std::min<int32_t>(kInChunk, n_trials - c0);
             const int64_t total = (int64_t)nk * E;
-            std::vector<int> bad((size_t)n_thr, 0);
-            if (total < (1 << 16) || n_thr == 1) {
-                log_rows(p_trials + (size_t)c0 * E, h.data(), total, is_log, &bad[0]);
-            } else {
-                std::vector<std::thread> thr;
-                for (int t = 0; t < n_thr; ++t) {
-                    const int64_t lo = total * t / n_thr, hi = total * (t + 1) / n_thr;
-                    thr.emplace_back(log_rows, p_trials + (size_t)c0 * E + lo, h.data() + lo, hi - lo, is_log, &bad[(size_t)t]);
-                }
-                for (auto& th : thr) th.join();
-            }
-            for (int v : bad)
-                if (v) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, is_log ? "a log-probability is NaN or above 0" : "a probability is outside [0,1]");
+            double* h = b->h_stage[turn];
+            HIP_TRY(ctx, hipEventSynchronize(b->ev_stage[turn])); // the copy out of this buffer two chunks ago (a never-recorded event is complete)
+            // glibc log on the host (the canonical logp of canopy_model_set_probabilities), on the library's worker threads,
+            // while the device copies and transposes the previous chunk
+            if (host_log_values(p_trials + (size_t)c0 * E, h, total, is_log) >= 0)
+                return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, is_log ? "a log-probability is NaN or above 0" : "a probability is outside [0,1]");
             if (total > 0) {
-                HIP_TRY(ctx, hipMemcpyAsync(b->d_in, h.data(), sizeof(double) * (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(ctx, hipMemcpyAsync(b->d_in, h, sizeof(double) * (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(ctx, hipEventRecord(b->ev_stage[turn], ctx->stream));
                 hipLaunchKernelGGL(k_batch_transpose, dim3((E + 63) / 64, (nk + 63) / 64), dim3(256), 0, ctx->stream,
                                    (const double*)b->d_in, nk, E, b->d_logpT, kpad, c0);
                 HIP_TRY(ctx, hipGetLastError());
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // h is reused by the next chunk
             }
         }
         b->host_log_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -497,17 +487,26 @@ canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* m, cons
     HIP_TRY(ctx, hipEventRecord(b->ev[0], ctx->stream));
     canopy_quant_params cprm = prm;
     cprm.flags = (prm.flags | CANOPY_QUANT_KEEP_MASK) & ~(uint32_t)CANOPY_QUANT_ROW_LOGP;
-    double* const saved_logp = m->d_logp;
-    const bool saved_has_p = m->has_p;
     const bool was_timing = ctx->timing_on;
-    m->d_logp = b->d_logp_max;
-    m->has_p = true;
-    ++m->logp_version; // the filter's quantised table must be rebuilt for the envelope ...
+    // the envelope is a probability set of its own (buffers of the batch state, written on the context's stream, which is
+    // also the stream the un-pipelined candidate pass runs on): the model's own sets are neither read nor changed
+    HIP_TRY(ctx, grow(&b->d_q8, &b->q8_cap, (((int64_t)E + 15) / 16) * 16 + 16));
+    HIP_TRY(ctx, grow(&b->d_fx, &b->fx_cap, (int64_t)(E > 0 ? E : 1)));
+    PSet envelope;
+    envelope.external = true;
+    envelope.d_logp = b->d_logp_max;
+    envelope.d_q8 = b->d_q8;
+    envelope.d_fx = b->d_fx;
+    envelope.write_stream = ctx->stream;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        envelope.version = ++m->logp_version; // (AUTO's feedback is keyed by it: never that of one of the model's sets)
+    }
     ctx->timing_on = false;
-    ctx->filter_only_request = true; // at scale AUTO runs FILTER_REFINE: only its filter is needed (lists instead of a mask)
     ctx->filter_only_done = false;
-    canopy_status st = canopy_quantify_async(ctx, m, &cprm);
-    ctx->filter_only_request = false;
+    PassOptions popt;
+    popt.filter_only = true; // at scale AUTO runs FILTER_REFINE: only its filter is needed (lists instead of a mask)
+    canopy_status st = enqueue_pass(ctx, m, &envelope, &cprm, popt);
     const bool fast = st == CANOPY_OK && ctx->filter_only_done;
     canopy_partial env;
     memset(&env, 0, sizeof(env));
@@ -549,9 +548,6 @@ canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* m, cons
             st = fail(ctx, e == hipErrorOutOfMemory ? CANOPY_ERR_OUT_OF_MEMORY : CANOPY_ERR_HIP, std::string("batch candidates: ") + hipGetErrorString(e));
         }
     }
-    m->d_logp = saved_logp;
-    m->has_p = saved_has_p;
-    ++m->logp_version; // ... and again for the model's own probabilities
     ctx->timing_on = was_timing;
     if (st != CANOPY_OK) return st;
     const int64_t n_words = (m->n_rows + 63) / 64;

@@ -1781,6 +1781,14 @@ bool fr_q8_overlapped(const FrP24* p24, int32_t n_events, int32_t max_row_len) {
 }
 void fr_q8_overlapped_units(int* unit_rows, int* units_per_slab) { *unit_rows = kQ8SlabRows; *units_per_slab = 1; } // (slab lists, as the plain filter's)
 
+// the 8-bit table of (logp, cut-off) by itself: q8_buf holds n_events bytes rounded up to 16
+hipError_t launch_fr_q8_table(const double* logp, int32_t n_events, double log_cut, uint8_t* q8_buf, hipStream_t s) {
+    const double mag = -log_cut > 1.0 ? -log_cut : 1.0;
+    const double inv_step = (double)kQ8Levels / mag;
+    hipLaunchKernelGGL(k_fr_q8_table, dim3(grid_for(n_events, 256)), dim3(256), 0, s, logp, n_events, inv_step, q8_buf);
+    return hipGetLastError();
+}
+
 hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool overlapped, int32_t max_row_len, const int64_t* fr_off,
                                int64_t total_chunks, const double* logp, uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs,
                                double log_cut, uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count,

@@ -267,11 +267,6 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(McArgs a) {
     }
 }
 
-canopy_status fail(canopy_ctx* ctx, canopy_status st, const std::string& msg) {
-    if (ctx) ctx->last_error = msg;
-    return st;
-}
-
 #define HIP_TRY(ctx, expr)                                                                              \
     do {                                                                                                \
         hipError_t _e = (expr);                                                                         \
@@ -487,12 +482,25 @@ canopy_status canopy_dag_set_probabilities(canopy_ctx* ctx, canopy_dag* d, const
     return CANOPY_OK;
 } CANOPY_CATCH_ALL
 
+void canopy_mc_params_default(canopy_mc_params* p) {
+    if (!p) return;
+    p->seed = 0;           // reference settings.h:324
+    p->first_sample = 0;
+    p->num_trials = 1000;  // settings.h:325
+    p->batch_size = 1;     // settings.h:326
+    p->sample_size = 1;    // settings.h:327
+}
+
 canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* d, const canopy_mc_params* prm) try {
     if (!ctx || !d || !prm) return CANOPY_ERR_INVALID_ARGUMENT;
     if (d->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "dag lives on another device");
     if (!d->has_p) return fail(ctx, CANOPY_ERR_STATE, "canopy_dag_set_probabilities has not been called");
-    if (prm->num_trials < 0 || prm->first_sample < 0 || (prm->first_sample & 63) != 0)
-        return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "num_trials >= 0 and first_sample a non-negative multiple of 64");
+    if (prm->num_trials < 0 || prm->first_sample < 0 || (prm->first_sample & 63) != 0 || prm->batch_size < 0 || prm->sample_size < 0)
+        return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "num_trials, batch_size, sample_size >= 0 and first_sample a non-negative multiple of 64");
+    // samples of this call: num_trials batches of batch_size trials of sample_size samples (reference settings.h:325-327; 0 reads as 1)
+    const __int128 wide = (__int128)prm->num_trials * (prm->batch_size > 0 ? prm->batch_size : 1) * (prm->sample_size > 0 ? prm->sample_size : 1);
+    if (wide > ((__int128)1 << 62)) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "num_trials * batch_size * sample_size exceeds 2^62");
+    const int64_t total = (int64_t)wide;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_mc_hits) {
         HIP_TRY(ctx, hipMalloc(&ctx->d_mc_hits, sizeof(unsigned long long)));
@@ -529,8 +537,8 @@ canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* d, const ca
     a.n_events = d->n_events; a.n_gates = d->n_gates; a.n_levels = d->n_levels; a.top = d->top; a.n_args = d->n_args; a.n_slots = d->n_slots;
     a.key = stream_key(prm->seed, kStreamMc);
     a.first_word = prm->first_sample / 64;
-    a.n_words = (prm->num_trials + 63) / 64;
-    a.num_trials = prm->num_trials;
+    a.n_words = (total + 63) / 64;
+    a.num_trials = total;
     a.hits = ctx->d_mc_hits;
     static const int mc_dbg = CANOPY_TUNE_ENV("CANOPY_MC_DEBUG") ? atoi(CANOPY_TUNE_ENV("CANOPY_MC_DEBUG")) : 0; // tuning only
     a.abl = mc_dbg;
@@ -569,11 +577,11 @@ canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* d, const ca
 #undef MC_GO
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->comm) { // shards of the sample range add: one u64 sum all-reduce of {hits, trials}
-        canopy_status cst = comm_all_reduce_mc(ctx, ctx->d_mc_hits, (long long)prm->num_trials);
+        canopy_status cst = comm_all_reduce_mc(ctx, ctx->d_mc_hits, (long long)total);
         if (cst != CANOPY_OK) return cst;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_mc[1], ctx->stream));
-    ctx->mc_last_trials = prm->num_trials;
+    ctx->mc_last_trials = total;
     return CANOPY_OK;
 } CANOPY_CATCH_ALL
 

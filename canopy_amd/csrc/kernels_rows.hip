@@ -187,15 +187,31 @@ __global__ __launch_bounds__(kRowsWaves * kWave) void k_rows(RowKernelArgs a) {
 }
 
 // Deterministic final reduce of the per-workgroup records (finalize_records in canopy_device.h).
+// host_rec: null, or 16 doubles of pinned host memory -- a ticketed pass publishes its record there ([0..8), and the
+// conservative pass's candidate total as a u64 at [8]), so that fetching it is an event wait and a memcpy, no device copy.
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ parts, int n, double* out,
-                                                  double* gather, int world, int rank, unsigned long long* fr_count) {
+                                                  double* gather, int world, int rank, unsigned long long* fr_count,
+                                                  double* host_rec) {
     __shared__ double s_red[4 * kAccDoubles];
     __shared__ double s_out[kAccDoubles];
     finalize_records(parts, n, out, gather, world, rank, s_red, s_out);
-    if (fr_count != nullptr && threadIdx.x == 0) { // FILTER_REFINE: last pass's candidate total for the host,
-        fr_count[1] = fr_count[0];                  // accumulator cleared for the next pass's filter
-        fr_count[0] = 0ULL;
+    if (host_rec != nullptr && threadIdx.x < kAccDoubles) host_rec[threadIdx.x] = s_out[threadIdx.x];
+    if (threadIdx.x == 0) {
+        unsigned long long total = 0ULL;
+        if (fr_count != nullptr) {       // FILTER_REFINE / FIXED_SUM: last pass's candidate total for the host,
+            total = fr_count[0];         // accumulator cleared for the next pass's conservative kernel
+            fr_count[1] = total;
+            fr_count[0] = 0ULL;
+        }
+        if (host_rec != nullptr) reinterpret_cast<unsigned long long*>(host_rec)[kAccDoubles] = total;
     }
+    if (host_rec != nullptr) __threadfence_system();
+}
+
+// the combined records behind the all-reduce of a ticketed pass, into pinned host memory
+__global__ __launch_bounds__(64) void k_publish(const double* __restrict__ src, int n, double* host_dst) {
+    for (int i = threadIdx.x; i < n; i += 64) host_dst[i] = src[i];
+    __threadfence_system();
 }
 
 } // namespace
@@ -226,8 +242,13 @@ hipError_t launch_rows_kernel(int variant, const RowKernelArgs& a, int grid, hip
 }
 
 hipError_t launch_finalize(const double* block_partials, int n_blocks, double* out, double* gather,
-                           int world, int rank, unsigned long long* fr_count, hipStream_t s) {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, block_partials, n_blocks, out, gather, world, rank, fr_count);
+                           int world, int rank, unsigned long long* fr_count, double* host_rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, block_partials, n_blocks, out, gather, world, rank, fr_count, host_rec);
+    return hipGetLastError();
+}
+
+hipError_t launch_publish(const double* src, int n, double* host_dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, src, n, host_dst);
     return hipGetLastError();
 }
 

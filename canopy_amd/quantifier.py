@@ -93,6 +93,25 @@ class Context:
         capi.check(capi.lib().canopy_quantify_async(self._h, model.handle, C.byref(params) if params else None),
                    "canopy_quantify_async", self._h)
 
+    def enqueue(self, model, params=None):
+        """quantify_async + a ticket: the pass's record can be fetched with ticket_fetch() while later passes run
+        (canopy_quantify_enqueue). At most three pipelined passes may be outstanding; fetch in enqueue order."""
+        t = C.c_uint64()
+        capi.check(capi.lib().canopy_quantify_enqueue(self._h, model.handle, C.byref(params) if params else None, C.byref(t)),
+                   "canopy_quantify_enqueue", self._h)
+        return t.value
+
+    def ticket_fetch(self, ticket):
+        """The shard record of the pass `ticket` (waits for that pass's lane only)."""
+        part = capi.Partial()
+        capi.check(capi.lib().canopy_ticket_fetch(self._h, ticket, C.byref(part)), "canopy_ticket_fetch", self._h)
+        return part
+
+    def ticket_done(self, ticket):
+        d = C.c_int32()
+        capi.check(capi.lib().canopy_ticket_done(self._h, ticket, C.byref(d)), "canopy_ticket_done", self._h)
+        return bool(d.value)
+
     def fetch_partial(self):
         part = capi.Partial()
         capi.check(capi.lib().canopy_quantify_fetch(self._h, C.byref(part)), "canopy_quantify_fetch", self._h)
@@ -241,6 +260,23 @@ class Comm:
         capi.check(capi.lib().canopy_comm_fetch(self._h, flags, C.byref(res), None), "canopy_comm_fetch", self._ctx.handle)
         return QuantResult(res.rare_event, res.mcub, res.n_kept, res.argmax_row, res.max_logp, -1.0)
 
+    def ticket_fetch(self, ticket, flags=0):
+        """Combined result of the pass `ticket` (canopy_comm_ticket_fetch: waits for that pass's lane only)."""
+        res = capi.QuantResult()
+        capi.check(capi.lib().canopy_comm_ticket_fetch(self._h, ticket, flags, C.byref(res), None), "canopy_comm_ticket_fetch",
+                   self._ctx.handle)
+        return QuantResult(res.rare_event, res.mcub, res.n_kept, res.argmax_row, res.max_logp, -1.0)
+
+    def ticket_partials(self, ticket):
+        parts = (capi.Partial * self.world)()
+        capi.check(capi.lib().canopy_comm_ticket_fetch(self._h, ticket, 0, None, parts), "canopy_comm_ticket_fetch",
+                   self._ctx.handle)
+        return list(parts)
+
+    def set_mode(self, mode):
+        """capi.COMM_CHAINED (default) / COMM_UNORDERED / COMM_OWN_STREAM: how consecutive collectives are ordered."""
+        capi.check(capi.lib().canopy_comm_set_mode(self._h, mode), "canopy_comm_set_mode", self._ctx.handle)
+
     def partials(self):
         parts = (capi.Partial * self.world)()
         capi.check(capi.lib().canopy_comm_fetch(self._h, 0, None, parts), "canopy_comm_fetch", self._ctx.handle)
@@ -301,8 +337,9 @@ class Dag:
         capi.check(capi.lib().canopy_dag_set_probabilities(self._ctx.handle, self._h, p.ctypes.data),
                    "canopy_dag_set_probabilities", self._ctx.handle)
 
-    def run_async(self, seed, num_trials, first_sample=0):
-        prm = capi.McParams(seed=seed, first_sample=first_sample, num_trials=num_trials)
+    def run_async(self, seed, num_trials, first_sample=0, batch_size=1, sample_size=1):
+        prm = capi.McParams(seed=seed, first_sample=first_sample, num_trials=num_trials, batch_size=batch_size,
+                            sample_size=sample_size)
         capi.check(capi.lib().canopy_mc_run_async(self._ctx.handle, self._h, C.byref(prm)), "canopy_mc_run_async",
                    self._ctx.handle)
 
@@ -311,8 +348,8 @@ class Dag:
         capi.check(capi.lib().canopy_mc_fetch(self._ctx.handle, C.byref(res)), "canopy_mc_fetch", self._ctx.handle)
         return res
 
-    def run(self, seed, num_trials, first_sample=0):
-        self.run_async(seed, num_trials, first_sample)
+    def run(self, seed, num_trials, first_sample=0, batch_size=1, sample_size=1):
+        self.run_async(seed, num_trials, first_sample, batch_size, sample_size)
         return self.fetch()
 
 
@@ -362,6 +399,14 @@ class Model:
             raise ValueError("p must have n_events entries")
         capi.check(capi.lib().canopy_model_set_probabilities(self._ctx.handle, self._h, p.ctypes.data),
                    "canopy_model_set_probabilities", self._ctx.handle)
+
+    def set_log_probabilities(self, logp):
+        """Caller-supplied natural logarithms (<= 0): no host log (canopy_model_set_log_probabilities)."""
+        logp = _as(logp, np.float64)
+        if logp.shape != (self.info().n_events,):
+            raise ValueError("logp must have n_events entries")
+        capi.check(capi.lib().canopy_model_set_log_probabilities(self._ctx.handle, self._h, logp.ctypes.data),
+                   "canopy_model_set_log_probabilities", self._ctx.handle)
 
 
 def default_params(cut_off=None, limit_order=None, flags=0, kernel=capi.KERNEL_AUTO):

@@ -79,6 +79,23 @@ public:
         check(canopy_quantify_fetch(get(), &p), "canopy_quantify_fetch");
         return p;
     }
+    // one result per pass while later passes run: enqueue() hands out a ticket, fetch(ticket) waits for that pass only
+    // (at most three pipelined passes outstanding, fetched in enqueue order)
+    canopy_ticket enqueue(const model_ptr& m, const canopy_quant_params& params = quant_params()) const {
+        canopy_ticket t = 0;
+        check(canopy_quantify_enqueue(get(), m.get(), &params, &t), "canopy_quantify_enqueue");
+        return t;
+    }
+    canopy_partial fetch(canopy_ticket t) const {
+        canopy_partial p;
+        check(canopy_ticket_fetch(get(), t, &p), "canopy_ticket_fetch");
+        return p;
+    }
+    void set_log_probabilities(const model_ptr& m, const std::vector<double>& logp) const {
+        if (logp.size() != (size_t)model_info(m).n_events)
+            throw error(CANOPY_ERR_INVALID_ARGUMENT, "set_log_probabilities", "logp must hold n_events values");
+        check(canopy_model_set_log_probabilities(get(), m.get(), logp.data()), "canopy_model_set_log_probabilities");
+    }
     // K probability vectors against one model (p_trials: n_trials x n_events, row-major); results[k] is what
     // quantify() returns after set_probabilities(p_trials[k]). info may be null.
     std::vector<canopy_quant_result> quantify_batch(const model_ptr& m, const std::vector<double>& p_trials, int32_t n_trials,

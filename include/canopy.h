@@ -25,9 +25,19 @@
  * Integer outputs are bit-exact against the oracle; rare/mcub agree to <= 1e-12 relative.
  *
  * Every entry point returns canopy_status; no exception crosses this boundary.
- * A canopy_ctx is bound to ONE device (one process per GPU); it is not thread-safe.
  * The library never falls back to a CPU path: without a usable HIP device
  * canopy_ctx_create fails with CANOPY_ERR_NO_DEVICE.
+ * The library reads NO environment variable (the tuning switches of benchmarks/ exist only in a
+ * -DCANOPY_ABLATIONS build).
+ *
+ * Threads. A canopy_ctx is bound to ONE device (one process per GPU) and is NOT thread-safe: one host
+ * thread at a time per context; distinct contexts may be driven from distinct threads. A canopy_model
+ * may be QUANTIFIED through several contexts of its device at once (also from several threads): a pass
+ * takes the model as const -- the derived layouts and tables a pass may have to build on first use
+ * are built once, under a mutex of the model. The calls that change a model
+ * (canopy_model_set_probabilities / _set_log_probabilities / _prepare / _free,
+ * canopy_quantify_batch*) must not overlap with any other call on the same model; when passes of
+ * another context still read the model, set_probabilities waits for the whole device first.
  */
 #ifndef CANOPY_CANOPY_H
 #define CANOPY_CANOPY_H
@@ -89,15 +99,17 @@ CANOPY_API const char* canopy_last_error(const canopy_ctx* ctx);
 /* Block the host until everything the context has enqueued (on its stream and on its side stream) has finished. */
 CANOPY_API canopy_status canopy_ctx_synchronize(canopy_ctx* ctx);
 /*
- * Pipelining of consecutive passes (default: on; CANOPY_NO_PIPELINE=1 in the environment turns it off for every
- * context). A sum-only FILTER_REFINE / FIXED_SUM pass is a row kernel that streams the whole model (HBM-bound, every
+ * Pipelining of consecutive passes (default: on). A sum-only FILTER_REFINE / FIXED_SUM pass is a row kernel that streams the whole model (HBM-bound, every
  * CU busy) followed by a latency-bound tail (exact pass over the listed rows, final reduce, and with a communicator
  * the all-reduce). With pipelining on, consecutive such passes rotate through three internal lanes -- a stream, scratch,
  * record and all-reduce slot buffer each -- and the device overlaps them: the next pass's row kernel takes the CUs as
  * this pass's row kernel leaves them, while this pass's tail runs beside it. A sequence of passes (uncertainty trials,
  * repeated quantification after canopy_model_set_probabilities, the benchmark's steps) is then paced by the row kernel
- * alone. Nothing changes for the caller: results are those of the LAST enqueued pass and are fetched as before (every
- * fetch / synchronize / set_probabilities call first orders the context's stream behind the other lanes); the host
+ * alone. canopy_quantify_fetch / canopy_comm_fetch deliver the LAST enqueued pass and wait for every lane;
+ * canopy_quantify_enqueue hands out a TICKET per pass instead, and canopy_ticket_fetch / canopy_comm_ticket_fetch wait
+ * for that pass's lane only -- a caller that needs every pass's result (uncertainty trials, a new probability vector
+ * per pass) keeps up to three passes in flight and still runs at the pipelined rate. canopy_model_set_probabilities
+ * does not drain the lanes either (it writes the next of the model's four probability sets). The host
  * may block in canopy_quantify_async until the pass three back has finished; passes that ask for per-row outputs,
  * keep masks or importance, all other kernel variants, and contexts with a caller-owned gather buffer
  * (canopy_ctx_set_gather_buffer) run un-pipelined on the context's stream behind whatever is still in flight.
@@ -171,6 +183,18 @@ CANOPY_API canopy_status canopy_model_download(canopy_ctx* ctx, const canopy_mod
  */
 CANOPY_API canopy_status canopy_model_set_probabilities(canopy_ctx* ctx, canopy_model* model,
                                                         const double* p);
+/*
+ * The same with the natural logarithms supplied by the caller (logp[E], each <= 0, -inf for p = 0): no host log.
+ * A caller that wants results identical to canopy_model_set_probabilities passes glibc's log(p[j]).
+ *
+ * Both calls are ASYNCHRONOUS towards the device and drain nothing: the values go (host log on the library's worker
+ * threads, then one copy from a pinned staging buffer) into the NEXT of four probability sets the model keeps; passes
+ * already enqueued keep reading the set they were enqueued with, the passes enqueued afterwards read the new one. The
+ * host array may be reused as soon as the call returns. Only while a captured pass (canopy_graph_capture) of the
+ * model exists is the current set rewritten in place, behind everything in flight.
+ */
+CANOPY_API canopy_status canopy_model_set_log_probabilities(canopy_ctx* ctx, canopy_model* model,
+                                                            const double* logp);
 
 /*
  * Build the derived device layout a kernel variant needs (today: the wave-slab stream of
@@ -258,8 +282,24 @@ typedef struct canopy_quant_result {
  */
 CANOPY_API canopy_status canopy_quantify_async(canopy_ctx* ctx, const canopy_model* model,
                                                const canopy_quant_params* params);
-/* Wait for the stream, copy the partial record to the host. */
+/* Wait for everything the context has enqueued, copy the partial record of the LAST pass to the host. */
 CANOPY_API canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* out);
+
+/*
+ * Tickets: one result per pass without serialising the passes. canopy_quantify_enqueue is canopy_quantify_async plus a
+ * ticket (the pass's number on this context, never 0); the pass's final reduce also writes its record into pinned host
+ * memory of the lane it ran on, so canopy_ticket_fetch is a wait for THAT lane's completion event and a memcpy -- no
+ * other lane is joined, no device copy is enqueued. A lane keeps the record of its last ticketed pass only: with
+ * pipelining on, a ticket stays valid until the third ticketed pipelined pass after it is enqueued (fetch in enqueue
+ * order, at most three outstanding); un-pipelined passes share one lane (fetch before the next enqueue). An expired
+ * ticket gives CANOPY_ERR_STATE. canopy_ticket_done polls without blocking. With a communicator attached
+ * (canopy_comm_init_rank) canopy_comm_ticket_fetch delivers the COMBINED result of the pass.
+ */
+typedef uint64_t canopy_ticket;
+CANOPY_API canopy_status canopy_quantify_enqueue(canopy_ctx* ctx, const canopy_model* model,
+                                                 const canopy_quant_params* params, canopy_ticket* ticket);
+CANOPY_API canopy_status canopy_ticket_fetch(canopy_ctx* ctx, canopy_ticket ticket, canopy_partial* out);
+CANOPY_API canopy_status canopy_ticket_done(canopy_ctx* ctx, canopy_ticket ticket, int32_t* done);
 /* Synchronous convenience: async + fetch + combine of the single shard; fills elapsed_kernel_ms. */
 CANOPY_API canopy_status canopy_quantify(canopy_ctx* ctx, const canopy_model* model,
                                          const canopy_quant_params* params,
@@ -296,13 +336,20 @@ CANOPY_API canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* dev
  * The fold over the world records is done on the host in rank order: bitwise identical on every rank.
  * Monte-Carlo (K6): with a communicator attached (process-per-GPU shape) canopy_mc_run_async also sums
  * {hits, trials} over the ranks (one u64 all-reduce); canopy_comm_mc_fetch returns the global estimate.
- * canopy_comm_free detaches (the context returns to single-shard behaviour); free it before its context.
+ * canopy_comm_free detaches (the context returns to single-shard behaviour); free it before its context
+ * (canopy_ctx_free takes a forgotten communicator with it).
  * Streams: the all-reduce is enqueued right behind the pass's final reduce, on the lane that ran it
  * (canopy_ctx_set_pipeline): the next pass's row kernel streams on another lane while the (latency-bound) collective
- * of this one is on the wire. Consecutive passes therefore call RCCL from different streams; RCCL chains its launches
- * through the communicator's internal stream. CANOPY_COMM_OWN_STREAM=1 in the environment instead gives the
- * communicator ONE stream of its own, each collective behind an event of its lane (two cross-queue edges per pass).
- * canopy_comm_fetch waits for the LAST enqueued pass.
+ * of this one is on the wire. Consecutive passes therefore issue the collectives of one communicator from different
+ * streams; canopy_comm_set_mode picks how they are ordered on the device:
+ *   CANOPY_COMM_CHAINED (default)  each collective waits for an event recorded behind the previous one: strict issue
+ *                                  order on the device, the same on every rank, by construction (one event edge per
+ *                                  pass, in the lane's latency-bound tail);
+ *   CANOPY_COMM_UNORDERED          no edge: RCCL chains a communicator's launches itself (saves the edge; relies on
+ *                                  RCCL's handling of one communicator on several streams);
+ *   CANOPY_COMM_OWN_STREAM         every collective on ONE stream of the communicator's own, behind an event of its
+ *                                  lane (two cross-queue edges per pass).
+ * canopy_comm_fetch waits for the LAST enqueued pass; canopy_comm_ticket_fetch for the pass of a ticket only.
  */
 #define CANOPY_COMM_ID_BYTES 128
 typedef struct canopy_comm_id { char bytes[CANOPY_COMM_ID_BYTES]; } canopy_comm_id;
@@ -318,6 +365,9 @@ CANOPY_API canopy_status canopy_comm_info(const canopy_comm* comm, int32_t* worl
                                           int32_t* rccl_version);
 CANOPY_API canopy_status canopy_comm_quantify_all_async(canopy_comm* const* comms, const canopy_model* const* models,
                                                         int32_t n, const canopy_quant_params* params);
+enum { CANOPY_COMM_CHAINED = 0, CANOPY_COMM_UNORDERED = 1, CANOPY_COMM_OWN_STREAM = 2 };
+/* Waits for everything in flight on the context, then switches. Every rank must use the same mode. */
+CANOPY_API canopy_status canopy_comm_set_mode(canopy_comm* comm, int32_t mode);
 
 /* Host-side, deterministic combine of n shard records in index order. */
 CANOPY_API canopy_status canopy_combine_partials(const canopy_partial* parts, int32_t n,
@@ -327,6 +377,10 @@ CANOPY_API canopy_status canopy_combine_partials(const canopy_partial* parts, in
    parts[world_size] may be NULL. flags: CANOPY_QUANT_CLAMP. */
 CANOPY_API canopy_status canopy_comm_fetch(canopy_comm* comm, uint32_t flags, canopy_quant_result* result,
                                            canopy_partial* parts);
+/* The same for the pass of a ticket (canopy_quantify_enqueue on the communicator's context): waits for that pass's lane
+   only. Every rank holds the same records, so every rank gets the same result. */
+CANOPY_API canopy_status canopy_comm_ticket_fetch(canopy_comm* comm, canopy_ticket ticket, uint32_t flags,
+                                                  canopy_quant_result* result, canopy_partial* parts);
 
 /* Device time of the last pass's all-reduce (event pair around it on the stream it ran on; waits for it). The pair is
    recorded for timed passes only -- the synchronous canopy_quantify, or a pass inside canopy_timing_begin/end --
@@ -468,14 +522,19 @@ CANOPY_API canopy_status canopy_dag_upload(canopy_ctx* ctx, const canopy_dag_vie
 CANOPY_API void canopy_dag_free(canopy_dag* dag);
 CANOPY_API canopy_status canopy_dag_set_probabilities(canopy_ctx* ctx, canopy_dag* dag, const double* p);
 
-/* (Settings::batch_size / sample_size, settings.h:129-151,326-327, exist in the reference as names with default 1 and no
-   stated meaning: a host that uses them as multipliers passes num_trials * batch_size * sample_size here. The sample
-   definition is counter-based, so a run may be cut into any number of calls by first_sample without changing a bit.) */
+/* Settings::batch_size / sample_size (settings.h:129-151,326-327) exist in the reference as names with default 1 and no
+   stated meaning; they are mirrored here as what a sampling loop of that shape computes: a run draws
+   num_trials * batch_size * sample_size Bernoulli samples per basic event ("num_trials batches of batch_size trials of
+   sample_size samples"), hits and num_trials of the result count samples. 0 is read as 1. The sample definition is
+   counter-based, so a run may be cut into any number of calls by first_sample without changing a bit. */
 typedef struct canopy_mc_params {
     uint64_t seed;        /* settings.h:324 */
     int64_t first_sample; /* global index of this shard's first sample, a multiple of 64 */
-    int64_t num_trials;   /* settings.h:325; samples drawn by THIS call */
+    int64_t num_trials;   /* settings.h:325 */
+    int32_t batch_size;   /* settings.h:326, default 1 */
+    int32_t sample_size;  /* settings.h:327, default 1 */
 } canopy_mc_params;
+CANOPY_API void canopy_mc_params_default(canopy_mc_params* params); /* seed 0, first_sample 0, num_trials 1000, 1, 1 */
 
 typedef struct canopy_mc_result {
     int64_t hits;
