@@ -47,7 +47,8 @@ class CsrView(C.Structure):
 class ModelInfo(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("nnz", C.c_int64), ("row_offset", C.c_int64),
                 ("n_events", C.c_int32), ("max_row_len", C.c_int32),
-                ("device_bytes", C.c_int64), ("stream_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64)]
+                ("device_bytes", C.c_int64), ("stream_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64),
+                ("stream_bytes_wide", C.c_int64)]
 
 
 class QuantParams(C.Structure):

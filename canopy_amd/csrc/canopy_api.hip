@@ -356,6 +356,9 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
     info->n_events = m->n_events; info->max_row_len = m->max_row_len;
     info->device_bytes = m->device_bytes;
     info->stream_bytes = 0;
+    info->stream_bytes_wide = 0;
+    if (m->fr_state == 1)
+        info->stream_bytes_wide = m->fr_total_chunks * 1024 + (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8 + (int64_t)m->n_events * 8;
     if (m->fr_state == 1) // what the quantised filter streams: the 24-bit form when the model has one
         info->stream_bytes = m->fr_total_chunks * (m->fr24.stream ? 768 + 4 : 1024) + (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8 +
                              m->n_fr_slabs * 8 + (int64_t)m->n_events * 8;

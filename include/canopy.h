@@ -168,6 +168,8 @@ typedef struct canopy_model_info {
                                    filter reads -- 24-bit entries when the model allows --, else the value-scatter or
                                    wave-slab stream), 0 if none is built */
     int64_t algorithmic_bytes;  /* (R+1)*8 + nnz*4 + E*8: compulsory traffic of one sum-only pass */
+    int64_t stream_bytes_wide;  /* bytes one pass over the 32-bit form of the slab stream reads (FIXED_SUM, the gathered filter:
+                                   4 B per entry in 1 KiB chunks + chunk offsets + the fixed-point table once), 0 without a slab stream */
 } canopy_model_info;
 
 CANOPY_API canopy_status canopy_model_get_info(const canopy_model* model, canopy_model_info* info);
