@@ -358,9 +358,16 @@ def main():
     def rec_tuple(parts):
         return tuple((q.rare_hi, q.rare_lo, q.log1p_hi, q.log1p_lo, q.n_kept, q.n_certain, q.max_logp, q.argmax_row) for q in parts)
 
+    depth = {"n": 3}  # steps in flight: three lanes when pipelined, ONE otherwise (un-pipelined passes share a lane,
+    #                    which keeps the record of its last ticketed pass only: fetch before the next enqueue)
+
+    def set_pipeline(on):
+        ctx.set_pipeline(on)
+        depth["n"] = 3 if on else 1
+
     def run_steps(n, set_p=None, fetch=True, prm_=None):
-        """n steps, each with its result fetched while up to two later steps are in flight. The torch-collective
-        fallback has no tickets: its steps are enqueued only."""
+        """n steps, each with its result fetched while up to two later steps are in flight (pipelined) or before the next
+        is enqueued (serial). The torch-collective fallback has no tickets: its steps are enqueued only."""
         prm_ = prm if prm_ is None else prm_
         inflight, last = [], None
         for i in range(n):
@@ -375,7 +382,7 @@ def main():
                 ctx.quantify_async(model, prm_)
                 continue
             inflight.append(ctx.enqueue(model, prm_))
-            if len(inflight) == 3:
+            if len(inflight) == depth["n"]:
                 last = fetch_ticket(inflight.pop(0))
         while inflight:
             last = fetch_ticket(inflight.pop(0))
@@ -389,7 +396,7 @@ def main():
             torch.cuda.synchronize()
 
     fetch_steps = not args.no_fetch
-    ctx.set_pipeline(not args.no_pipeline)
+    set_pipeline(not args.no_pipeline)
     pipeline_note = ""
 
     # ---- N > 1: a pipelined burst must deliver what a serial pass delivers, record for record, on every rank ----
@@ -398,9 +405,9 @@ def main():
         dog.arm("pipelined-burst verification")
         ok_local, why = True, ""
         try:
-            ctx.set_pipeline(False)
+            set_pipeline(False)
             serial_rec = rec_tuple(fetch_ticket(ctx.enqueue(model, prm)))
-            ctx.set_pipeline(True)
+            set_pipeline(True)
             tickets, burst = [], []
             for i in range(9):  # three rounds over the three lanes, at most three in flight
                 tickets.append(ctx.enqueue(model, prm))
@@ -422,7 +429,7 @@ def main():
             pipeline_note = "pipelining switched off on every rank: " + (why or "another rank reported a mismatch")
             sys.stderr.write("[bench] rank %d: %s\n" % (rank, pipeline_note))
             args.no_pipeline = True
-            ctx.set_pipeline(False)
+            set_pipeline(False)
 
     dog.arm("spin-up + warm-up")
     run_steps(args.spinup, fetch=fetch_steps)  # setup, like the model build: not a warm-up step, not timed
@@ -447,7 +454,7 @@ def main():
     # ---- the serial form, un-instrumented, same fetch discipline: what a strictly one-at-a-time caller sees ----
     dog.arm("serial leg")
     serial_steps = max(10, min(args.steps, 50))
-    ctx.set_pipeline(False)
+    set_pipeline(False)
     run_steps(5, fetch=fetch_steps)
     fence()
     t0 = time.perf_counter()
@@ -478,7 +485,7 @@ def main():
     fence()
     k_ms_sum, tot_ms_sum, n_timed = ctx.timing_end()
     launches = ctx.timing_launches(n_timed)
-    ctx.set_pipeline(not args.no_pipeline)
+    set_pipeline(not args.no_pipeline)
     dog.disarm()
 
     if comm is not None:
@@ -546,7 +553,7 @@ def main():
             for i in range(n):
                 set_log(i)
                 inflight.append(ctx.enqueue(model, prm))
-                if len(inflight) == 3:
+                if len(inflight) == depth["n"]:
                     last_ = fetch_ticket(inflight.pop(0))
             while inflight:
                 last_ = fetch_ticket(inflight.pop(0))
@@ -582,14 +589,14 @@ def main():
         ctx.synchronize()
         t_prep0 = time.time() - t0
         el0, _ = timed_leg(args.also_steps, prm0)
-        ctx.set_pipeline(False)  # instrumented serial probe, as for the headline
+        set_pipeline(False)  # instrumented serial probe, as for the headline
         ctx.timing_begin(args.also_steps)
         for _ in range(args.also_steps):
             ctx.quantify_async(model, prm0)
         ctx.synchronize()
         _, _, n0 = ctx.timing_end()
         l0 = ctx.timing_launches(n0)
-        ctx.set_pipeline(not args.no_pipeline)
+        set_pipeline(not args.no_pipeline)
         r0 = canopy_amd.combine_partials([ctx.fetch_partial()])
         cand0 = ctx.last_filter_candidates()
         v0 = ctx.last_kernel_variant()
@@ -689,8 +696,8 @@ def main():
             },
             "serial": {"ms_per_step": serial_elapsed * 1e3 / serial_steps, "steps": serial_steps,
                        "value": total_rows * serial_steps / serial_elapsed,
-                       "what": "the same steps with pipelining off (one pass at a time, result fetched before the next is enqueued "
-                               "two later): what a caller that never overlaps passes sees"},
+                       "what": "the same steps with pipelining off: one pass at a time, its result fetched before the next is "
+                               "enqueued -- what a caller that never overlaps passes sees"},
             "per_rank": per_rank,
             "result": {"rare_event": result.rare_event, "mcub": result.mcub, "n_kept": result.n_kept,
                        "argmax_row": result.argmax_row},
