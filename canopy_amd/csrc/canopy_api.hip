@@ -58,6 +58,8 @@ void free_model_buffers(canopy_model* m) {
     if (m->fr24.base) (void)hipFree(m->fr24.base);
     if (m->fr24.exc) (void)hipFree(m->fr24.exc);
     m->fr24 = FrP24Owned();
+    if (m->d_off16) (void)hipFree(m->d_off16);
+    m->d_off16 = nullptr;
     m->d_vs_stream = nullptr; m->d_vs_off = nullptr; m->d_vs_slab_row = nullptr; m->vs_state = 0;
     m->d_row_ptr = nullptr; m->d_col_idx = nullptr;
     m->d_ws_stream = nullptr; m->d_ws_off = nullptr; m->ws_state = 0;

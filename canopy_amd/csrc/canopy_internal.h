@@ -256,6 +256,7 @@ struct canopy_model {
     mutable int64_t* d_fr_off = nullptr;
     mutable int64_t fr_total_chunks = 0, n_fr_slabs = 0;
     mutable FrP24Owned fr24; // 24-bit form of the same chunks (quantised filter), or nulls
+    mutable uint16_t* d_off16 = nullptr; // [n_rows + 1] row start minus the start of the row's 8192-row block (null: some block holds > 65535 entries)
     mutable int fr_state = 0;
 };
 
@@ -273,6 +274,7 @@ struct RowKernelArgs {
     double* block_partials; // [grid][8]
     double* row_logp_out;   // nullable
     uint64_t* keep_mask_out;// nullable
+    const uint16_t* off16 = nullptr; // nullable: row starts relative to their 8192-row block (exact pass of the two-step variants)
 };
 
 // kernels_rows.hip
@@ -366,6 +368,8 @@ hipError_t fr_build_sorted32(const int64_t* d_row_ptr, const int32_t* d_col_idx,
                              const int64_t* d_fr_off, int64_t total_chunks, int64_t n_slabs, uint32_t** d_stream_out,
                              hipStream_t s);
 int fr_slab_rows(int32_t n_events);
+// 2-byte row offsets for the exact pass (null when a block of 8192 rows holds more than 65535 entries); waits for the stream
+hipError_t fr_build_off16(const int64_t* d_row_ptr, int64_t n_rows, uint16_t** d_off16_out, hipStream_t s);
 hipError_t launch_fr_filter(const uint32_t* stream, const int64_t* fr_off, int64_t total_chunks, const double* logp,
                             int64_t n_rows, int32_t n_events, int64_t n_slabs, double cand_cut, uint16_t* cand_list,
                             unsigned* cand_cnt, unsigned long long* cand_count, int n_cu, hipStream_t s);

@@ -1081,21 +1081,51 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8po(const uint4* __re
 // reproducible. The exact keep bits are OR-ed into a pre-cleared mask when the caller wants one.
 constexpr int kRefineWaves = 4;
 
-__device__ __forceinline__ double refine_row_sum(const RowKernelArgs& a, int64_t r, int* len_out) {
-    const int64_t b = a.row_ptr[r], e = a.row_ptr[r + 1];
+constexpr int kOffBlockBits = 13; // d_off16: row starts relative to their 8192-row block
+
+struct __attribute__((packed, aligned(4))) Cols4 { int32_t c[4]; }; // one 16-byte load at 4-byte alignment (col_idx has 64 B of slack)
+
+// Bounds of row r. With the 2-byte offsets a candidate costs a 2-byte pair out of a 128-byte line that serves 64 rows
+// (the int64 row_ptr line serves 16): what the exact pass pays per listed row at HBM is lines, not bytes.
+__device__ __forceinline__ void refine_row_bounds(const RowKernelArgs& a, int64_t r, int64_t* b_out, int* len_out) {
+    if (a.off16 != nullptr) {
+        const int64_t blk = (r >> kOffBlockBits) << kOffBlockBits;
+        const int64_t base = a.row_ptr[blk]; // the lanes of a list unit share their block: one address
+        const int64_t nxt = r + 1;
+        const int64_t b = base + (int64_t)a.off16[r];
+        const int64_t e = ((nxt & ((1 << kOffBlockBits) - 1)) == 0 || nxt == a.n_rows) ? a.row_ptr[nxt] : base + (int64_t)a.off16[nxt];
+        *b_out = b;
+        *len_out = (int)(e - b);
+    } else {
+        const int64_t b = a.row_ptr[r], e = a.row_ptr[r + 1];
+        *b_out = b;
+        *len_out = (int)(e - b);
+    }
+}
+
+// The exact CSR-order sum of one row per lane. Columns come four at a time in 16-byte loads, table entries as one gather per
+// entry position the longest row of the WAVE still has (wave-uniform trip counts: no per-lane predicated loads).
+__device__ __forceinline__ double refine_row_sum(const RowKernelArgs& a, int64_t b, int len, bool on) {
+    int wave_max = len;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(wave_max, d, kWave); wave_max = o > wave_max ? o : wave_max; }
+    wave_max = __builtin_amdgcn_readfirstlane(wave_max);
     double s = 0.0;
-    // 8 entries at a time: all column loads, then all table loads, then the adds in CSR order
-    for (int64_t k0 = b; k0 < e; k0 += 8) {
+    for (int k0 = 0; k0 < wave_max; k0 += 8) {
+        const int n_here = wave_max - k0 < 8 ? wave_max - k0 : 8; // wave-uniform
+        Cols4 q0, q1;
+        q0 = *reinterpret_cast<const Cols4*>(a.col_idx + (on ? b + k0 : 0));
+        if (n_here > 4) q1 = *reinterpret_cast<const Cols4*>(a.col_idx + (on ? b + k0 + 4 : 0));
+        else { q1.c[0] = q1.c[1] = q1.c[2] = q1.c[3] = 0; }
         int32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { c[u] = (k0 + u < len) ? q0.c[u] : 0; c[4 + u] = (k0 + 4 + u < len) ? q1.c[u] : 0; }
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = (k0 + u < e) ? a.col_idx[k0 + u] : 0;
+        for (int u = 0; u < 8; ++u) if (u < n_here) v[u] = a.logp[c[u]];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = a.logp[c[u]];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (k0 + u < e) s = s + v[u]; // plain adds, CSR order
+        for (int u = 0; u < 8; ++u) if (u < n_here && k0 + u < len) s = s + v[u]; // plain adds, CSR order
     }
-    *len_out = (int)(e - b);
     return s;
 }
 
@@ -1126,7 +1156,9 @@ __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArg
             const bool account = !FLAGGED || (entry & 0x8000u) != 0, contend = !FLAGGED || (entry & 0x4000u) != 0;
             const int64_t r = base + (int64_t)(FLAGGED ? (entry & 0x3FFFu) : entry);
             int len = 0;
-            const double sv = on ? refine_row_sum(a, r, &len) : 0.0;
+            int64_t rb = 0;
+            if (on) refine_row_bounds(a, r, &rb, &len);
+            const double sv = refine_row_sum(a, rb, len, on);
             const bool keep = on && (sv >= a.log_cut) && (a.limit_order == 0 || len <= a.limit_order);
             fold_kept_row(acc.rare, acc.l1p, acc.n_certain, sv, keep && account);
             if (keep) {
@@ -1674,6 +1706,41 @@ hipError_t fr_build_pack24(const uint32_t* d_stream32, const int64_t* d_fr_off, 
 int fr_max_events() { return 1 << 18; }
 bool fr_filter_is_quantised(int32_t n_events) { return fr_use_q8(n_events) && fr_slab_rows_for(n_events) == 8192; }
 int fr_refine_grid(int n_cu) { return n_cu * 8; }
+
+namespace {
+__global__ void k_fr_off16(const int64_t* __restrict__ row_ptr, int64_t n_rows, uint16_t* __restrict__ off16, int* __restrict__ too_wide) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t blk = (r >> kOffBlockBits) << kOffBlockBits;
+        const int64_t d = row_ptr[r] - row_ptr[blk];
+        if (d > 65535) atomicOr(too_wide, 1);
+        off16[r] = (uint16_t)d;
+    }
+}
+} // namespace
+
+hipError_t fr_build_off16(const int64_t* d_row_ptr, int64_t n_rows, uint16_t** d_off16_out, hipStream_t s) {
+    *d_off16_out = nullptr;
+    uint16_t* d = nullptr;
+    int* flag = nullptr;
+    hipError_t e = hipMalloc(&d, sizeof(uint16_t) * (size_t)(n_rows + 1));
+    if (e == hipSuccess) e = hipMalloc(&flag, sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    int wide = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_fr_off16, dim3(grid_for(n_rows + 1, 256) > 65535 * 4 ? 65535 * 4 : grid_for(n_rows + 1, 256)), dim3(256), 0, s,
+                           d_row_ptr, n_rows, d, flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&wide, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (flag) (void)hipFree(flag);
+    if (e != hipSuccess || wide) { // (a block with > 65535 entries: the exact pass keeps reading the int64 offsets)
+        if (d) (void)hipFree(d);
+        return e;
+    }
+    *d_off16_out = d;
+    return hipSuccess;
+}
 int fr_slab_rows(int32_t n_events) { return fr_slab_rows_for(n_events); }
 
 // Chunk offsets of the (slab, part) pairs: fr_off[s * H + h], H = fr_parts_for(n_events) (1 up to 112 K events).

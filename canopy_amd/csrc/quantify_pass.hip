@@ -91,6 +91,9 @@ canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m) {
         return drop(e, "fr_build_pack24");
     }
     m->device_bytes += (m->fr_total_chunks + 1) * 1024 + (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8;
+    e = fr_build_off16(m->d_row_ptr, m->n_rows, &m->d_off16, ctx->stream); // 2 B per row: what the exact pass reads instead of row_ptr
+    if (e != hipSuccess) { (void)hipGetLastError(); m->d_off16 = nullptr; }  // (optional layout: the pass runs without it)
+    if (m->d_off16) m->device_bytes += (m->n_rows + 1) * 2;
     if (m->fr24.stream) {
         m->device_bytes += (m->fr_total_chunks + 1) * (768 + 4) + (m->n_fr_slabs + 1) * 4;
         // the quantised filter reads the 24-bit form only: the 32-bit stream goes, and comes back (ensure_fr32, ~15 ms at
@@ -463,6 +466,7 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
     a.block_partials = S.d_block_partials;
     a.row_logp_out = pl.want_rows ? ctx->d_row_logp : nullptr;
     a.keep_mask_out = pl.want_mask ? ctx->d_keep_mask : nullptr;
+    a.off16 = pl.two_step ? m->d_off16 : nullptr;
 
     // HIP events around the pass only when somebody will read them (a timing region, or the synchronous canopy_quantify):
     // every record is a marker packet between two kernels, ~5 us of queue time at the 1.25e7-row shard of an 8-GPU run
