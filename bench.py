@@ -215,7 +215,6 @@ def traffic_for(variant, info, cut_off):
 
 KERNEL_LABELS = {1: "k_rows (lane per row, L2 gather)", 2: "k_rows (lane per row, LDS table)",
                  3: "k_ws (wave-slab stream, exact CSR-order sums)", 4: "k_vs (value scatter)",
-                 7: "k_ps (part sweep: exact CSR-order sums, the table gathered from LDS part by part)",
                  5: "k_fr_filter_q8 + k_fr_refine (quantised conservative filter, then exact refine)",
                  6: "k_fx2 + k_fr_refine (order-independent fixed-point sums, exact refine of the undecided rows)"}
 
@@ -242,7 +241,7 @@ def moved_bytes(variant, info, listed_rows):
         return info.stream_bytes + (listed_rows or 0) * (2 * 128 + 4)
     if variant == 6 and info.stream_bytes_wide:  # the fixed-point pass streams the 32-bit form of the slab stream
         return info.stream_bytes_wide + (listed_rows or 0) * (2 * 128 + 4)
-    if variant in (3, 4, 7) and info.stream_bytes:
+    if variant in (3, 4) and info.stream_bytes:
         return info.stream_bytes
     return info.algorithmic_bytes
 

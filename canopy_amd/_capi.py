@@ -32,8 +32,7 @@ QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK, QUANT_IMPORTANCE = 1, 2, 4, 8
 BATCH_LOG_INPUT = 1
 GATE_AND, GATE_OR, GATE_ATLEAST, GATE_XOR, GATE_NOT, GATE_NAND, GATE_NOR, GATE_NULL = range(8)
 COMM_CHAINED, COMM_UNORDERED, COMM_OWN_STREAM = 0, 1, 2
-KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER, KERNEL_FILTER_REFINE, KERNEL_FIXED_SUM, \
-    KERNEL_PART_SWEEP = range(8)
+KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER, KERNEL_FILTER_REFINE, KERNEL_FIXED_SUM = range(7)
 
 
 class CtxParams(C.Structure):

@@ -46,9 +46,6 @@ void free_model_buffers(canopy_model* m) {
         P = PSet();
     }
     m->cur = -1;
-    if (m->d_ps_stream) (void)hipFree(m->d_ps_stream);
-    if (m->d_ps_goff) (void)hipFree(m->d_ps_goff);
-    m->d_ps_stream = nullptr; m->d_ps_goff = nullptr; m->ps_state = 0;
     if (m->d_ws_stream) (void)hipFree(m->d_ws_stream);
     if (m->d_ws_off) (void)hipFree(m->d_ws_off);
     if (m->d_vs_stream) (void)hipFree(m->d_vs_stream);
@@ -369,8 +366,6 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
                              m->n_fr_slabs * 8 + (int64_t)m->n_events * 8;
     else if (m->vs_state == 1)
         info->stream_bytes = m->vs_total_chunks * 1024 + (m->n_slabs + 1) * 16 + (m->n_rows + 1) * 8 + (int64_t)m->n_events * 8;
-    else if (m->ps_state == 1)
-        info->stream_bytes = m->ps_total_groups * 256 + (m->n_ps * ps_parts(m->n_events) + 1) * 4 + (int64_t)m->n_events * 8;
     else if (m->ws_state == 1)
         info->stream_bytes = m->ws_total_chunks * 1024 + (m->n_ws + 1) * 8 + (int64_t)m->n_events * 8;
     info->algorithmic_bytes = (m->n_rows + 1) * 8 + m->nnz * 4 + (int64_t)m->n_events * 8;
@@ -400,7 +395,7 @@ canopy_status set_values(canopy_ctx* ctx, canopy_model* m, const double* v, bool
     if (!ctx || !m || (!v && m->n_events > 0)) return CANOPY_ERR_INVALID_ARGUMENT;
     if (m->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "model lives on another device");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t ev = (size_t)(m->n_events > 0 ? m->n_events : 1) + 2; // (+2: the part-sweep kernel loads the table 16 bytes at a time)
+    const size_t ev = (size_t)(m->n_events > 0 ? m->n_events : 1);
     const bool in_place = m->graph_refs > 0 && m->cur >= 0;
     const int slot = m->cur < 0 ? 0 : (in_place ? m->cur : (m->cur + 1) % kPSets);
     PSet& P = m->psets[slot];
@@ -482,12 +477,6 @@ canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, int32_t ker
         if (kernel == CANOPY_KERNEL_VALUE_SCATTER)
             return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a value-scatter stream");
         return CANOPY_OK; // AUTO: quantify falls back to ROWS
-    }
-    if (variant == CANOPY_KERNEL_PART_SWEEP) {
-        canopy_status st = build_ps(ctx, m);
-        if (st != CANOPY_OK) return st;
-        if (m->ps_state != 1) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a part stream");
-        return CANOPY_OK;
     }
     if (variant != CANOPY_KERNEL_WAVE_STREAM) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
     canopy_status st = build_ws(ctx, m);

@@ -245,11 +245,6 @@ struct canopy_model {
     mutable int64_t* d_ws_off = nullptr;
     mutable int64_t ws_total_chunks = 0, n_ws = 0;
     mutable int ws_state = 0; // 0 not built, 1 ready, -1 not representable (fall back to ROWS)
-    // derived part stream (kernels_ws.hip, PART_SWEEP)
-    mutable uint32_t* d_ps_stream = nullptr;
-    mutable uint32_t* d_ps_goff = nullptr;
-    mutable int64_t ps_total_groups = 0, n_ps = 0;
-    mutable int ps_state = 0;
     // derived value-scatter layout (kernels_vs.hip)
     mutable uint32_t* d_vs_stream = nullptr;
     mutable int64_t* d_vs_off = nullptr;
@@ -326,7 +321,6 @@ canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m);
 canopy_status ensure_fr32(canopy_ctx* ctx, const canopy_model* m);
 canopy_status build_vs(canopy_ctx* ctx, const canopy_model* m);
 canopy_status build_ws(canopy_ctx* ctx, const canopy_model* m);
-canopy_status build_ps(canopy_ctx* ctx, const canopy_model* m);
 int auto_variant(const canopy_model* m);
 int64_t fr_min_rows(int base_variant);
 canopy_status fail(canopy_ctx* ctx, canopy_status st, const std::string& msg);
@@ -352,16 +346,6 @@ hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, con
                             int64_t total_chunks, int64_t n_ws, int need_len, int grid, int* n_records,
                             hipStream_t s);
 
-
-// kernels_ws.hip, PART_SWEEP: wave-owned row sums, the table gathered from LDS part by part
-int ps_parts(int32_t n_events);
-int ps_max_events();
-int ps_default_grid(int n_cu, int64_t n_ws);
-hipError_t ps_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events, int32_t max_row_len,
-                    uint32_t** d_stream_out, uint32_t** d_goff_out, int64_t* total_groups_out, int64_t* n_ws_out, bool* ok,
-                    hipStream_t s);
-hipError_t launch_ps_kernel(const RowKernelArgs& ra, const uint32_t* stream, const uint32_t* goff, int64_t n_ws, int need_len,
-                            int grid, hipStream_t s);
 
 // kernels_vs.hip
 int vs_max_events();

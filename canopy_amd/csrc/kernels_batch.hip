@@ -447,7 +447,7 @@ canopy_status canopy_quantify_batch_async(canopy_ctx* ctx, canopy_model* m, cons
 
     // ---- 1. host logs (threaded), staged in chunks of trials, transposed on the device to [E][kpad]
     HIP_TRY(ctx, grow(&b->d_logpT, &b->logpT_cap, (int64_t)E * kpad));
-    HIP_TRY(ctx, grow(&b->d_logp_max, &b->max_cap, (int64_t)E + 2)); // (+2: 16-byte table loads of the part-sweep kernel)
+    HIP_TRY(ctx, grow(&b->d_logp_max, &b->max_cap, (int64_t)E));
     HIP_TRY(ctx, grow(&b->d_in, &b->in_cap, (int64_t)std::min<int32_t>(kInChunk, n_trials) * E));
     {
         const auto t0 = std::chrono::steady_clock::now();

@@ -448,384 +448,4 @@ hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, con
     return launch_ws_t<4096, 8, 0>(ra, stream, ws_off, sc, grid, s);
 }
 
-
-// =====================================================================================================================
-// PART_SWEEP (round 3): the same wave-owned row sums, with the table gathered from LDS instead of through the texture path.
-//
-// What bounds every exact pass that gathers the fp64 table through L1/L2 is the texture addresser: a 64-lane gather costs
-// it ~2.2 clocks per 128-byte line touched (profiles/r03_microbench_gather_floor.txt: 29 clocks at 9 lines per instruction,
-// 60 at 25, 109 at 47), and the fewer rows a wave or workgroup owns the sparser its column-sorted entries are. An LDS
-// gather costs 13-16 clocks whatever the addresses. So: the columns are cut into PARTS of 8192 (64 KB of table), a
-// workgroup of 8 waves owns a slab-set of 8 x 1024 rows, and for every part in turn it (1) puts the part of the table into
-// LDS with coalesced loads (the L2 feeds the 0.8 MB table at > 25 TB/s), (2) every wave adds the entries of ITS 1024 rows
-// that fall into the part -- ds_read_b64 of the value, ds_add_f64 into the row's sum in the wave's private LDS slice.
-// Parts ascend, columns ascend inside a row, a wave's LDS operations execute in issue order, the 64 entries of an
-// instruction hit 64 distinct rows: row i receives exactly ((logp[c0] + logp[c1]) + ...) in CSR order -- bit-exact per-row
-// sums with NO gather through the texture path and no ordering constraint between waves.
-//
-// Stream ("part stream"): for every (wave-slab, part) a run of groups of 64 packed entries
-//   u32 = col_in_part (14 bits: 0..8191, 8192 = the table's zero slot) << 11 | row_local (11 bits: 0..1023, 1024.. = sinks)
-// a group holds 64 distinct rows, a row's entries sit in strictly increasing groups; the runs of a wave-slab follow each
-// other part by part; goff[ws * H + h] = first group of the run. Padding = "zero slot -> sink row lane k".
-// =====================================================================================================================
-namespace {
-
-constexpr int kPsRows = 1024;   // rows per wave
-constexpr int kPsWaves = 8;     // waves per workgroup: a slab-set of 8192 rows, one workgroup per CU
-constexpr int kPsPartBits = 13; // 8192 columns per part
-constexpr int kPsPart = 1 << kPsPartBits;
-constexpr int kPsRowBits = 11;
-constexpr int kPsSlots = kPsRows + 64;
-constexpr int kPsGP = 10;       // groups of one (wave-slab, part) that travel in registers (the rest is loaded when needed)
-constexpr size_t kPsTabBytes = (size_t)(kPsPart + 2) * 8;
-constexpr size_t kPsLdsBytes = kPsTabBytes + (size_t)kPsWaves * kPsSlots * 8;
-constexpr int kPsMaxParts = 63; // the offsets of a wave-slab travel in one VGPR, lane h = part h
-
-__device__ __host__ constexpr uint32_t ps_pad_entry(int lane) { return ((uint32_t)kPsPart << kPsRowBits) | (uint32_t)(kPsRows + lane); }
-
-// builder: one thread per (wave-slab, part), greedy and sequential => deterministic. WRITE = false counts the groups.
-template <bool WRITE>
-__global__ __launch_bounds__(64) void k_ps_build(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
-                                                 int64_t n_rows, int H, int64_t n_tasks, int gcap, uint8_t* cnt_scratch,
-                                                 int64_t* ng /* [n_tasks] out (count pass) */, const int64_t* __restrict__ goff,
-                                                 uint32_t* stream, int* overflow) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tasks) return;
-    const int64_t ws = t / H;
-    const int h = (int)(t - ws * H);
-    const int64_t r0 = ws * kPsRows;
-    const int64_t r1 = r0 + kPsRows < n_rows ? r0 + kPsRows : n_rows;
-    uint8_t* cnt = cnt_scratch + (size_t)t * gcap;
-    for (int g = 0; g < gcap; ++g) cnt[g] = 0;
-    int lo = 0, g_max = -1;
-    const int64_t base = WRITE ? goff[t] * kGroup : 0;
-    bool ovf = false;
-    // Two walks: first the rows with SEVERAL entries in this part (each needs a chain of increasing groups: placed while the
-    // groups are empty, the chains start at the front), then the rows with one entry, which fill every hole from the lowest
-    // group up -- the run ends up with ceil(entries / 64) groups unless a chain is longer than that.
-    for (int pass = 0; pass < 2 && !ovf; ++pass) {
-        for (int64_t r = r0; r < r1 && !ovf; ++r) {
-            const int64_t b = row_ptr[r], e = row_ptr[r + 1];
-            int64_t kb = e, ke = e; // the row's entries in part h: [kb, ke)
-            for (int64_t k = b; k < e; ++k) {
-                const int part = (int)((uint32_t)col_idx[k] >> kPsPartBits);
-                if (part < h) continue;
-                if (part == h && kb == e) kb = k;
-                if (part > h) { ke = k; break; } // columns ascend inside a row
-            }
-            if (kb == e) continue;
-            const bool chain = ke - kb > 1;
-            if (chain != (pass == 0)) continue;
-            int g_prev = -1;
-            for (int64_t k = kb; k < ke; ++k) {
-                const uint32_t c = (uint32_t)col_idx[k];
-                int g = g_prev + 1 > lo ? g_prev + 1 : lo;
-                while (g < gcap && cnt[g] >= kGroup) ++g;
-                if (g >= gcap) { ovf = true; break; }
-                const int slot = cnt[g]++;
-                if (WRITE) stream[base + (int64_t)g * kGroup + slot] = ((c & (uint32_t)(kPsPart - 1)) << kPsRowBits) | (uint32_t)(r - r0);
-                g_prev = g;
-                g_max = g > g_max ? g : g_max;
-                while (lo < gcap && cnt[lo] >= kGroup) ++lo;
-            }
-        }
-    }
-    if (ovf) atomicExch(overflow, 1);
-    if (!WRITE) ng[t] = (int64_t)(g_max + 1);
-}
-
-__global__ __launch_bounds__(256) void k_ps_fill(uint32_t* p, int64_t n) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = ps_pad_entry((int)(i & 63));
-}
-
-__global__ __launch_bounds__(256) void k_ps_narrow(const int64_t* __restrict__ src, uint32_t* __restrict__ dst, int64_t n) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (uint32_t)src[i];
-}
-
-struct PsScalars {
-    int64_t n_rows, n_ws, row_offset;
-    double log_cut;
-    int32_t limit_order, need_len, H, n_events;
-};
-
-__device__ __forceinline__ uint32_t ps_lane_u32(uint32_t v, int lane_idx) { // v's value in lane `lane_idx` (wave-uniform index)
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_idx);
-}
-
-// one group of 64 entries: value out of the LDS table, add into the owner row's LDS sum
-#define PS_GROUP4(E0, E1, E2, E3)                                                                                         \
-    do {                                                                                                                  \
-        const uint32_t e_[4] = {E0, E1, E2, E3};                                                                          \
-        double v_[4];                                                                                                     \
-        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) v_[u_] = (ABL & 4) ? (double)e_[u_] : tab[e_[u_] >> kPsRowBits];    \
-        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                                 \
-            if (ABL & 1) asm volatile("" ::"v"(v_[u_]), "v"(e_[u_]));                                                      \
-            else __hip_atomic_fetch_add(&sums[e_[u_] & ((1u << kPsRowBits) - 1)], v_[u_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); \
-        }                                                                                                                 \
-    } while (0)
-
-// ABL (CANOPY_ABLATIONS builds only; wrong results): 1 no LDS adds, 2 no table swap, 4 no table reads, 8 no epilogue
-template <bool MULTI, int ABL = 0> // MULTI: more than one column part (the table part in LDS changes); else the whole table stays resident
-__global__ __launch_bounds__(kPsWaves * kWave) void k_ps(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ goff,
-                                                         const double* __restrict__ logp, const int64_t* __restrict__ row_ptr,
-                                                         PsScalars sc, double* __restrict__ block_partials,
-                                                         double* __restrict__ row_logp_out, uint64_t* __restrict__ keep_mask_out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    double* tab = reinterpret_cast<double*>(smem);
-    double* sums = reinterpret_cast<double*>(smem + kPsTabBytes) + (size_t)wave * kPsSlots;
-    for (int i = lane; i < kPsSlots; i += kWave) sums[i] = 0.0;
-    if (tid < 2) tab[kPsPart + tid] = 0.0; // the zero slot padding entries read
-
-    Acc acc;
-    acc_init(acc);
-    const int H = sc.H;
-    const int64_t G = (int64_t)gridDim.x;
-    const int64_t n_ss = (sc.n_ws + kPsWaves - 1) / kPsWaves;
-    const uint32_t pad = ps_pad_entry(lane);
-
-    // the H + 1 group offsets of a wave-slab in ONE register: lane h holds goff[ws * H + h]
-    auto load_offsets = [&](int64_t ss_) -> uint32_t {
-        const int64_t ws_ = ss_ * kPsWaves + wave;
-        return (ss_ < n_ss && ws_ < sc.n_ws && lane <= H) ? goff[ws_ * H + lane] : 0u;
-    };
-    // the table part of 8192 columns: 16 bytes per thread, 8 times (zeros beyond the last column)
-    double2 tq[8], tr[8]; // the next part of the table, and the one after it (two parts of look-ahead, like the stream)
-    // (every logp table carries two doubles of slack behind its last column: the 16-byte load of an odd last column is valid)
-    auto load_table = [&](int h_) { // no branch around a load: clamped addresses, the values selected afterwards
-        const int64_t c0 = (int64_t)h_ * kPsPart;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int64_t c = c0 + k * 1024 + tid * 2;
-            const bool in1 = c < sc.n_events, in2 = c + 1 < sc.n_events;
-            double2 v = *reinterpret_cast<const double2*>(logp + (in1 ? c : 0));
-            v.x = in1 ? v.x : 0.0;
-            v.y = in2 ? v.y : 0.0;
-            tr[k] = v;
-        }
-    };
-    auto store_table = [&]() { // the older set goes into LDS, the younger one moves up
-#pragma unroll
-        for (int k = 0; k < 8; ++k) *reinterpret_cast<double2*>(tab + k * 1024 + tid * 2) = tq[k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) tq[k] = tr[k];
-    };
-
-    // Register sets of stream groups: the part being added, and the two parts after it (their loads are in flight).
-    uint32_t qa[kPsGP], qb[kPsGP], qc[kPsGP];
-    int na = 0, nb = 0, nc = 0;       // groups of the run each set belongs to (wave-uniform)
-    uint32_t ga = 0, gb = 0, gc = 0;  // first group of that run
-    // position two parts ahead of the current one: slab-set f_ss (0, 1 or 2 slab-sets ahead), part f_h
-    int64_t ss = blockIdx.x;
-    uint32_t off0 = load_offsets(ss), off1 = load_offsets(ss + G), off2 = load_offsets(ss + 2 * G);
-    uint32_t off3 = load_offsets(ss + 3 * G); // in flight for a whole slab-set: nothing reads it before it has moved down
-    int64_t f_ss = ss;
-    int f_h = 0;
-    int f_rel = 0; // (f_ss - ss) / G
-#define PS_ISSUE(QF, NF, GF)                                                                                              \
-    do { /* loads of the run at the look-ahead position into set F; then the position moves on by one part */           \
-        const uint32_t offv_ = f_rel == 0 ? off0 : (f_rel == 1 ? off1 : off2);                                            \
-        const uint32_t g0_ = ps_lane_u32(offv_, f_h), g1_ = ps_lane_u32(offv_, f_h + 1);                                   \
-        GF = g0_;                                                                                                         \
-        NF = f_ss < n_ss ? (int)(g1_ - g0_) : 0;                                                                          \
-        /* unconditional loads (a branch around a load makes the compiler drain the memory queue): positions past the  \
-           run's end re-read its last group (a cache hit), never used */                                               \
-        _Pragma("unroll") for (int k_ = 0; k_ < kPsGP; ++k_)                                                              \
-            QF[k_] = stream[((size_t)g0_ + (k_ < NF ? k_ : (NF > 0 ? NF - 1 : 0))) * kGroup + lane];                       \
-        if (++f_h == H) { f_h = 0; f_ss += G; ++f_rel; }                                                                   \
-    } while (0)
-#define PS_ADD(QC, NC, GC)                                                                                                \
-    do { /* every group of the current run: the first kPsGP out of registers, a longer run's rest straight from memory */ \
-        _Pragma("unroll") for (int k_ = 0; k_ < kPsGP; k_ += 4)                                                           \
-            if (k_ < NC)                                                                                                  \
-                PS_GROUP4(QC[k_], k_ + 1 < NC ? QC[k_ + 1] : pad, k_ + 2 < NC ? QC[k_ + 2] : pad, k_ + 3 < NC ? QC[k_ + 3] : pad); \
-        for (int k_ = kPsGP; k_ < NC; k_ += 4) {                                                                          \
-            uint32_t x_[4];                                                                                               \
-            _Pragma("unroll") for (int u2_ = 0; u2_ < 4; ++u2_)                                                           \
-                x_[u2_] = k_ + u2_ < NC ? stream[((size_t)GC + k_ + u2_) * kGroup + lane] : pad;                           \
-            PS_GROUP4(x_[0], x_[1], x_[2], x_[3]);                                                                        \
-        }                                                                                                                 \
-    } while (0)
-#define PS_PART(QC, NC, GC, QF, NF, GF)                                                                                   \
-    do {                                                                                                                  \
-        if (swap_table && !(ABL & 2)) {                                                                                   \
-            __syncthreads(); /* every wave has finished reading the previous part of the table */                         \
-            store_table();                                                                                                \
-            __syncthreads();                                                                                              \
-        }                                                                                                                 \
-        if (MULTI) { /* the part of the table two parts ahead into registers (a few times too often at the very end) */     \
-            load_table((h + 2) % H);                                                                                      \
-            swap_table = h + 1 < H || ss + G < n_ss;                                                                      \
-        } else swap_table = false;                                                                                        \
-        PS_ISSUE(QF, NF, GF);                                                                                             \
-        PS_ADD(QC, NC, GC);                                                                                               \
-        if (++h == H) { /* the slab-set is complete: fold this wave's 1024 rows, move on */                               \
-            const int64_t ws_ = ss * kPsWaves + wave;                                                                     \
-            if (ws_ < sc.n_ws && !(ABL & 8))                                                                              \
-                ws_epilogue<kPsRows>(sums, ws_, lane, &acc, sc.n_rows, sc.row_offset, sc.log_cut, sc.limit_order, sc.need_len, \
-                                     row_ptr, row_logp_out, keep_mask_out, 0, kPsRows / kWave);                           \
-            h = 0;                                                                                                        \
-            ss += G;                                                                                                      \
-            off0 = off1; off1 = off2; off2 = off3; off3 = load_offsets(ss + 3 * G);                                       \
-            --f_rel;                                                                                                      \
-        }                                                                                                                 \
-    } while (0)
-
-    if (ss < n_ss) {
-        bool swap_table = true; // the first part always goes into LDS
-        load_table(0);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) tq[k] = tr[k];
-        load_table(H > 1 ? 1 : 0);
-        int h = 0;
-        PS_ISSUE(qa, na, ga); // the first two runs; from here on every part issues the run two parts ahead
-        PS_ISSUE(qb, nb, gb);
-        while (ss < n_ss) {
-            PS_PART(qa, na, ga, qc, nc, gc);
-            if (ss >= n_ss) break;
-            PS_PART(qb, nb, gb, qa, na, ga);
-            if (ss >= n_ss) break;
-            PS_PART(qc, nc, gc, qb, nb, gb);
-        }
-    }
-#undef PS_PART
-#undef PS_ADD
-#undef PS_ISSUE
-
-    // workgroup reduce of the wave records (the sums slices are dead now)
-    __syncthreads();
-    double* s_red = reinterpret_cast<double*>(smem);
-    acc_wave_reduce(acc);
-    if (lane == 0) acc_store(s_red + wave * kAccDoubles, acc);
-    __syncthreads();
-    if (tid == 0) {
-        Acc r;
-        acc_load(r, s_red);
-        for (int w = 1; w < kPsWaves; ++w) {
-            Acc o;
-            acc_load(o, s_red + w * kAccDoubles);
-            acc_merge(r, o);
-        }
-        acc_store(block_partials + (size_t)blockIdx.x * kAccDoubles, r);
-    }
-}
-#undef PS_GROUP4
-
-} // namespace
-
-int ps_parts(int32_t n_events) { return n_events <= 0 ? 1 : (int)(((int64_t)n_events + kPsPart - 1) / kPsPart); }
-int ps_max_events() { return kPsMaxParts * kPsPart; }
-int ps_default_grid(int n_cu, int64_t n_ws) {
-    int64_t g = (n_ws + kPsWaves - 1) / kPsWaves;
-    if (g > n_cu) g = n_cu; // one workgroup per CU: its LDS holds a table part and 8192 row sums
-    return g < 1 ? 1 : (int)g;
-}
-
-// Builds the part stream of the model's canonical CSR. *ok = false: the model does not fit (too many parts, absurd rows,
-// more than 2^32 groups): the caller keeps another variant.
-hipError_t ps_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events, int32_t max_row_len,
-                    uint32_t** d_stream_out, uint32_t** d_goff_out, int64_t* total_groups_out, int64_t* n_ws_out, bool* ok,
-                    hipStream_t s) {
-    *ok = false;
-    *d_stream_out = nullptr; *d_goff_out = nullptr; *total_groups_out = 0;
-    const int H = ps_parts(n_events);
-    const int64_t n_ws = (n_rows + kPsRows - 1) / kPsRows;
-    *n_ws_out = n_ws;
-    if (H > kPsMaxParts) return hipSuccess;
-    const int64_t n_tasks = n_ws * H;
-    int64_t gcap64 = ((int64_t)kPsRows * (max_row_len > 0 ? max_row_len : 1) + kGroup - 1) / kGroup + (max_row_len > 0 ? max_row_len : 1) + 2;
-    if (gcap64 > 4096 || (double)gcap64 * (double)(n_tasks > 0 ? n_tasks : 1) > 3.0e9) return hipSuccess; // absurd rows / scratch
-    const int gcap = (int)gcap64;
-    uint8_t* d_cnt = nullptr;
-    int64_t* d_off = nullptr;
-    uint32_t* d_goff = nullptr;
-    int* d_ovf = nullptr;
-    uint32_t* d_stream = nullptr;
-    auto bail = [&](hipError_t err) {
-        if (d_cnt) (void)hipFree(d_cnt);
-        if (d_off) (void)hipFree(d_off);
-        if (d_goff) (void)hipFree(d_goff);
-        if (d_ovf) (void)hipFree(d_ovf);
-        if (d_stream) (void)hipFree(d_stream);
-        return err;
-    };
-    hipError_t e = hipMalloc(&d_cnt, (size_t)(n_tasks > 0 ? n_tasks : 1) * gcap);
-    if (e == hipSuccess) e = hipMalloc(&d_off, sizeof(int64_t) * (size_t)(n_tasks + 1));
-    if (e == hipSuccess) e = hipMalloc(&d_goff, sizeof(uint32_t) * (size_t)(n_tasks + 1 + kWave)); // (+64: a wave reads lanes 0..H of its slice)
-    if (e == hipSuccess) e = hipMalloc(&d_ovf, sizeof(int));
-    if (e == hipSuccess) e = hipMemsetAsync(d_ovf, 0, sizeof(int), s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_off, 0, sizeof(int64_t), s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_goff, 0, sizeof(uint32_t) * (size_t)(n_tasks + 1 + kWave), s);
-    if (e != hipSuccess) return bail(e);
-    int64_t total = 0;
-    int ovf = 0;
-    if (n_tasks > 0) {
-        hipLaunchKernelGGL((k_ps_build<false>), dim3(grid_for(n_tasks, 64)), dim3(64), 0, s, d_row_ptr, d_col_idx, n_rows, H, n_tasks, gcap,
-                           d_cnt, d_off + 1, (const int64_t*)nullptr, (uint32_t*)nullptr, d_ovf);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = scan_inclusive_i64(d_off + 1, n_tasks, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(&ovf, d_ovf, sizeof(int), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(&total, d_off + n_tasks, sizeof(int64_t), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return bail(e);
-        if (ovf || total >= ((int64_t)1 << 32) - kPsGP) { (void)bail(hipSuccess); return hipSuccess; }
-    }
-    const int64_t n_entries = (total + kPsGP) * kGroup; // (+ padding groups a predicated look-ahead may touch)
-    e = hipMalloc(&d_stream, sizeof(uint32_t) * (size_t)n_entries);
-    if (e != hipSuccess) return bail(e);
-    hipLaunchKernelGGL(k_ps_fill, dim3(grid_for(n_entries, 256) > 4096 ? 4096 : grid_for(n_entries, 256)), dim3(256), 0, s, d_stream, n_entries);
-    if (n_tasks > 0) {
-        hipLaunchKernelGGL((k_ps_build<true>), dim3(grid_for(n_tasks, 64)), dim3(64), 0, s, d_row_ptr, d_col_idx, n_rows, H, n_tasks, gcap,
-                           d_cnt, (int64_t*)nullptr, (const int64_t*)d_off, d_stream, d_ovf);
-        hipLaunchKernelGGL(k_ps_narrow, dim3(grid_for(n_tasks + 1, 256) > 4096 ? 4096 : grid_for(n_tasks + 1, 256)), dim3(256), 0, s,
-                           (const int64_t*)d_off, d_goff, n_tasks + 1);
-    }
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return bail(e);
-    (void)hipFree(d_cnt);
-    (void)hipFree(d_off);
-    (void)hipFree(d_ovf);
-    *d_stream_out = d_stream;
-    *d_goff_out = d_goff;
-    *total_groups_out = total;
-    *ok = true;
-    return hipSuccess;
-}
-
-hipError_t launch_ps_kernel(const RowKernelArgs& ra, const uint32_t* stream, const uint32_t* goff, int64_t n_ws, int need_len,
-                            int grid, hipStream_t s) {
-    PsScalars sc;
-    sc.n_rows = ra.n_rows; sc.n_ws = n_ws; sc.row_offset = ra.row_offset;
-    sc.log_cut = ra.log_cut; sc.limit_order = ra.limit_order; sc.need_len = need_len;
-    sc.H = ps_parts(ra.n_events); sc.n_events = ra.n_events;
-#define PS_GO(M, A)                                                                                                       \
-    do { /* (the LDS attribute is per device: set on every launch) */                                                     \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ps<M, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        if (e_ != hipSuccess) return e_;                                                                                  \
-        hipLaunchKernelGGL((k_ps<M, A>), dim3(grid), dim3(kPsWaves * kWave), kPsLdsBytes, s, stream, goff, ra.logp, ra.row_ptr, sc,  \
-                           ra.block_partials, ra.row_logp_out, ra.keep_mask_out);                                         \
-        return hipGetLastError();                                                                                         \
-    } while (0)
-#ifdef CANOPY_ABLATIONS // timing ablations of benchmarks/ (wrong results)
-    static const int dbg = CANOPY_TUNE_ENV("CANOPY_PS_DEBUG") ? atoi(CANOPY_TUNE_ENV("CANOPY_PS_DEBUG")) : 0;
-    if (sc.H > 1) {
-        if (dbg == 1) PS_GO(true, 1);
-        if (dbg == 2) PS_GO(true, 2);
-        if (dbg == 4) PS_GO(true, 4);
-        if (dbg == 5) PS_GO(true, 5);
-        if (dbg == 7) PS_GO(true, 7);
-        if (dbg == 8) PS_GO(true, 8);
-        if (dbg == 15) PS_GO(true, 15);
-    }
-#endif
-    if (sc.H > 1) PS_GO(true, 0);
-    PS_GO(false, 0);
-#undef PS_GO
-}
-
 } // namespace canopy

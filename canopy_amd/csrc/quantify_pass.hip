@@ -145,17 +145,6 @@ canopy_status build_ws(canopy_ctx* ctx, const canopy_model* m) {
     return CANOPY_OK;
 }
 
-canopy_status build_ps(canopy_ctx* ctx, const canopy_model* m) {
-    std::lock_guard<std::mutex> lk(m->mu);
-    if (m->ps_state != 0) return CANOPY_OK;
-    bool ok = false;
-    HIP_TRY(ctx, ps_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, m->max_row_len, &m->d_ps_stream, &m->d_ps_goff,
-                          &m->ps_total_groups, &m->n_ps, &ok, ctx->stream));
-    m->ps_state = ok ? 1 : -1;
-    if (ok) m->device_bytes += (m->ps_total_groups + 12) * 256 + (m->n_ps * ps_parts(m->n_events) + 65) * 4;
-    return CANOPY_OK;
-}
-
 // ---- probability sets: ordering between the stream that wrote a set and the lanes that read it -------------------
 
 hipError_t order_behind_set(canopy_ctx::PassScratch& S, hipStream_t lane, const canopy_model* m, int slot) {
@@ -279,7 +268,7 @@ canopy_status plan_pass(canopy_ctx* ctx, const canopy_model* m, const PSet* P, c
         if (variant == CANOPY_KERNEL_FIXED_SUM && m->max_row_len > fx_max_row_len())
             return fail(ctx, CANOPY_ERR_UNSUPPORTED, "FIXED_SUM needs rows of at most 63 entries");
     } else if (variant != CANOPY_KERNEL_ROWS && variant != CANOPY_KERNEL_ROWS_LDS && variant != CANOPY_KERNEL_WAVE_STREAM &&
-               variant != CANOPY_KERNEL_VALUE_SCATTER && variant != CANOPY_KERNEL_PART_SWEEP) {
+               variant != CANOPY_KERNEL_VALUE_SCATTER) {
         return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
     }
     if (variant == CANOPY_KERNEL_ROWS_LDS && (size_t)m->n_events > rows_lds_table_limit_events())
@@ -313,15 +302,6 @@ canopy_status ensure_layouts(canopy_ctx* ctx, const canopy_model* m, const canop
             if (params->kernel == CANOPY_KERNEL_VALUE_SCATTER)
                 return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a value-scatter stream");
             pl.variant = CANOPY_KERNEL_ROWS;
-        }
-    }
-    if (pl.variant == CANOPY_KERNEL_PART_SWEEP) {
-        canopy_status pst = build_ps(ctx, m);
-        if (pst != CANOPY_OK) return pst;
-        if (m->ps_state != 1) {
-            if (params->kernel == CANOPY_KERNEL_PART_SWEEP)
-                return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a part stream");
-            pl.variant = CANOPY_KERNEL_WAVE_STREAM; // AUTO: the other exact stream kernel
         }
     }
     if (pl.variant == CANOPY_KERNEL_WAVE_STREAM) {
@@ -553,9 +533,6 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
     } else if (pl.variant == CANOPY_KERNEL_VALUE_SCATTER) {
         HIP_TRY(ctx, launch_vs_kernel(a, m->d_vs_stream, m->d_vs_off, m->d_vs_slab_row, m->vs_total_chunks, m->n_slabs,
                                       grid, ctx->stream));
-    } else if (pl.variant == CANOPY_KERNEL_PART_SWEEP) {
-        const int need_len = (params->limit_order != 0 && params->limit_order < m->max_row_len) ? 1 : 0;
-        HIP_TRY(ctx, launch_ps_kernel(a, m->d_ps_stream, m->d_ps_goff, m->n_ps, need_len, grid, ctx->stream));
     } else if (pl.variant == CANOPY_KERNEL_WAVE_STREAM) {
         const int need_len = (params->limit_order != 0 && params->limit_order < m->max_row_len) ? 1 : 0;
         HIP_TRY(ctx, launch_ws_kernel(a, m->d_ws_stream, m->d_ws_off, m->ws_total_chunks, m->n_ws, need_len, grid,
@@ -620,9 +597,7 @@ canopy_status enqueue_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, cons
     st = ensure_outputs(ctx, m, pl);
     if (st != CANOPY_OK) return st;
 
-    if (pl.variant == CANOPY_KERNEL_PART_SWEEP)
-        pl.grid = ps_default_grid(ctx->n_cu, m->n_ps);
-    else if (pl.variant == CANOPY_KERNEL_WAVE_STREAM)
+    if (pl.variant == CANOPY_KERNEL_WAVE_STREAM)
         pl.grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : ws_default_grid(ctx->n_cu, m->n_ws);
     else if (pl.variant == CANOPY_KERNEL_VALUE_SCATTER)
         pl.grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : vs_default_grid(ctx->n_cu, m->n_slabs);

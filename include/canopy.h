@@ -241,9 +241,6 @@ enum {
     CANOPY_KERNEL_FILTER_REFINE = 5, /* cut_off > 0, no per-row output: a fast unordered pass flags the rows
                                        that might survive, an exact CSR-order pass recomputes only those.
                                        Reported values are exactly those of the other variants. */
-    CANOPY_KERNEL_PART_SWEEP = 7,   /* derived layout: exact CSR-order sums like WAVE_STREAM (per-row output, any cut-off), the
-                                       table gathered from LDS: the columns are cut into parts of 8192, a workgroup sweeps its
-                                       8192 rows part by part with the part of the table resident in LDS (E <= 516096) */
     CANOPY_KERNEL_FIXED_SUM = 6     /* no per-row output, rows of <= 63 entries: every row summed in 2^-47 fixed point
                                        (integer adds commute, so all waves share a slab: no ordering constraint),
                                        exp / log1p taken from that sum (|error| <= L*2^-48 + L*|s|*2^-53, inside the

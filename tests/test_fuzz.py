@@ -70,8 +70,6 @@ def test_random_models_every_variant(gpu_ctx, oracle, seed):
         kernels.append(_capi.KERNEL_ROWS_LDS)
     if max_len <= 4095:
         kernels.append(_capi.KERNEL_VALUE_SCATTER)
-    if n_events <= 63 * 8192 and max_len <= 60:
-        kernels.append(_capi.KERNEL_PART_SWEEP)
     for kern in kernels:
         got = gpu_ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order, kernel=kern,
                                                      flags=_capi.QUANT_ROW_LOGP | _capi.QUANT_KEEP_MASK))

@@ -32,8 +32,6 @@ def variants(n_events, max_row_len=10, cut_off=0.0):
         v.append(_capi.KERNEL_ROWS_LDS)
     if n_events <= (1 << 19):
         v.append(_capi.KERNEL_WAVE_STREAM)
-    if n_events <= 63 * 8192 and max_row_len <= 60:
-        v.append(_capi.KERNEL_PART_SWEEP)  # exact CSR-order sums, table parts in LDS (round 3)
     if n_events <= (1 << 18) and max_row_len <= 4095:
         v.append(_capi.KERNEL_VALUE_SCATTER)
     if 1 <= n_events <= (1 << 18) and cut_off > 0:
