@@ -65,6 +65,9 @@ def parse_args(argv=None):
                     help="lib: canopy_comm_* (ncclAllReduce issued by libcanopy.so); torch: torch.distributed all_reduce")
     ap.add_argument("--comm-mode", choices=("chained", "unordered", "own-stream"), default="chained",
                     help="how consecutive collectives of the communicator are ordered on the device (canopy_comm_set_mode)")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="lanes consecutive passes rotate through (2..4); 0 = what measured best: 4 for the whole model on one GPU "
+                         "(0.330 against 0.336 ms per step), 3 for the short passes of a shard (45.9 against 49.0 us at the 8-way size)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="A/B: passes strictly one after the other on one stream (canopy_ctx_set_pipeline(0))")
     ap.add_argument("--no-fetch", action="store_true", help="A/B: the timed steps are enqueued without fetching their records")
@@ -361,9 +364,11 @@ def main():
     depth = {"n": 3}  # steps in flight: three lanes when pipelined, ONE otherwise (un-pipelined passes share a lane,
     #                    which keeps the record of its last ticketed pass only: fetch before the next enqueue)
 
+    lanes = args.lanes if args.lanes >= 2 else (3 if (world > 1 or args.force_dist or args.shard_of > 1) else 4)
+
     def set_pipeline(on):
-        ctx.set_pipeline(on)
-        depth["n"] = 3 if on else 1
+        ctx.set_pipeline(lanes if on else 0)
+        depth["n"] = lanes if on else 1
 
     def run_steps(n, set_p=None, fetch=True, prm_=None):
         """n steps, each with its result fetched while up to two later steps are in flight (pipelined) or before the next
@@ -409,9 +414,9 @@ def main():
             serial_rec = rec_tuple(fetch_ticket(ctx.enqueue(model, prm)))
             set_pipeline(True)
             tickets, burst = [], []
-            for i in range(9):  # three rounds over the three lanes, at most three in flight
+            for i in range(9):  # more than two rounds over the lanes, as many in flight as there are lanes
                 tickets.append(ctx.enqueue(model, prm))
-                if len(tickets) == 3:
+                if len(tickets) == lanes:
                     burst.append(rec_tuple(fetch_ticket(tickets.pop(0))))
             while tickets:
                 burst.append(rec_tuple(fetch_ticket(tickets.pop(0))))
@@ -690,7 +695,7 @@ def main():
                 "serial_pass_ms_note": "pass = row kernels + final reduce (+ all-reduce at N > 1), one pass at a time",
                 "host_enqueue_ms_per_step": t_enqueued * 1e3 / args.steps,
                 "collective_ms": {"median": c_med, "max": c_max, "passes": len(coll_ms)} if coll_ms else None,
-                "pipelined": not args.no_pipeline, "pipeline_note": pipeline_note or None,
+                "pipelined": not args.no_pipeline, "lanes": lanes if not args.no_pipeline else 1, "pipeline_note": pipeline_note or None,
                 "verification": verify,
                 "probe": "kernel / pass ms: %d instrumented serial passes after the timed region" % n_timed,
             },

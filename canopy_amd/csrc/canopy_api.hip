@@ -159,7 +159,7 @@ canopy_status canopy_ctx_create(const canopy_ctx_params* params, canopy_ctx** ou
             if (st == CANOPY_OK && hipHostMalloc(&S.h_rec, sizeof(double) * 2 * CANOPY_PARTIAL_DOUBLES) != hipSuccess) st = CANOPY_ERR_OUT_OF_MEMORY;
         }
         if (st != CANOPY_OK) break;
-        static const bool no_pipe = CANOPY_TUNE_ENV("CANOPY_NO_PIPELINE") != nullptr;
+        static const bool no_pipe = CANOPY_TUNE_ENV("CANOPY_NO_PIPELINE") != nullptr; // tuning only
         ctx->pipeline_on = !no_pipe;
     } while (0);
     if (st != CANOPY_OK) {
@@ -219,7 +219,11 @@ canopy_status canopy_ctx_set_pipeline(canopy_ctx* ctx, int32_t enable) try {
     if (!ctx) return CANOPY_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, canopy::ctx_join_side(ctx));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // nothing in flight while the rotation changes
+    for (auto& S : ctx->sets) { S.pending_lo = 0; S.pending = false; }
     ctx->pipeline_on = enable != 0;
+    ctx->n_lanes = enable >= 2 ? (enable > canopy_ctx::kLanes ? canopy_ctx::kLanes : enable) : 3;
+    if (ctx->pipe_next >= ctx->n_lanes) ctx->pipe_next = 0;
     return CANOPY_OK;
 } CANOPY_CATCH_ALL
 

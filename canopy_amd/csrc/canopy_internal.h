@@ -31,7 +31,7 @@ void batch_state_free(BatchState* b);
 // passes still in flight keep reading the sets they were enqueued with -- a new probability vector does not drain the
 // lanes of a context. Writes into a set (the upload, a table build) are followed by a record of ev_write on the stream
 // they were enqueued on; a pass on any other stream waits for that record once (PassScratch::seen_write).
-constexpr int kPSets = 4;
+constexpr int kPSets = 6; // more than the lanes of a context plus the set being written
 struct PSet {
     double* d_logp = nullptr;     // [n_events]
     uint8_t* d_q8 = nullptr;      // [n_events rounded up to 16] + 16: quantised -logp of the conservative filter
@@ -78,7 +78,7 @@ struct canopy_ctx {
     // when already satisfied): the host blocks before it reuses a lane until that lane's previous pass has finished.
     // Lane 0 is the context's own stream; passes with per-row outputs and the other kernel variants run there, behind
     // everything the other lanes still hold.
-    static constexpr int kLanes = 3;
+    static constexpr int kLanes = 4; // at most; n_lanes of them rotate (canopy_ctx_set_pipeline: default 3)
     struct PassScratch {
         hipStream_t stream = nullptr;       // lane 0: the context's stream
         double* d_block_partials = nullptr; // [block_partials_cap][8]
@@ -100,7 +100,7 @@ struct canopy_ctx {
         bool last_has_event = false;        // ev_done was recorded behind the lane's last pass
         // probability sets this lane is already ordered behind (model id, write ids per set)
         uint64_t seen_model = 0;
-        uint64_t seen_write[canopy::kPSets] = {0, 0, 0, 0};
+        uint64_t seen_write[canopy::kPSets] = {};
         // AUTO's feedback (how many rows the conservative pass listed) belongs to the lane that ran the pass
         uint64_t fb_model = 0;              // model id of the lane's last two-step pass (0 = none / consumed)
         int64_t fb_rows = 0;
@@ -108,7 +108,8 @@ struct canopy_ctx {
         uint64_t fb_version = 0;
         int32_t fb_variant = 0;
     } sets[kLanes];
-    bool pipeline_on = true;      // canopy_ctx_set_pipeline / CANOPY_NO_PIPELINE
+    bool pipeline_on = true;      // canopy_ctx_set_pipeline
+    int n_lanes = 3;              // lanes consecutive pipelined passes rotate through (2 .. kLanes)
     int pipe_next = 0;            // lane of the next pipelined pass
     int last_set = 0;             // lane of the last pass (its record and candidate count are fetched from there)
     double* d_partial = nullptr;        // the shard record, 8 doubles
@@ -170,7 +171,7 @@ struct canopy_comm {
     int world = 1, rank = 0;
     double* d_buf = nullptr; // [lanes][world][8] gather slots = the all-reduce buffers, one per lane of the context
     double* h_buf = nullptr; // pinned mirror
-    double* h_lane[canopy_ctx::kLanes] = {nullptr, nullptr, nullptr}; // pinned [world][8]: the combined records of a lane's last ticketed pass
+    double* h_lane[canopy_ctx::kLanes] = {}; // pinned [world][8]: the combined records of a lane's last ticketed pass
     // Ordering of consecutive collectives (canopy_comm_set_mode). CHAINED (default): the collective rides the lane that
     // ran the final reduce, behind an event recorded after the PREVIOUS collective of this communicator -- the device
     // runs the collectives of one communicator strictly in issue order whatever stream they are on. UNORDERED: no such
@@ -178,7 +179,7 @@ struct canopy_comm {
     // the lane whose final reduce filled the buffer.
     int32_t mode = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_lane[canopy_ctx::kLanes] = {nullptr, nullptr, nullptr}; // "this lane's record is in its slot buffer"
+    hipEvent_t ev_lane[canopy_ctx::kLanes] = {}; // "this lane's record is in its slot buffer"
     hipEvent_t ev_chain[2] = {nullptr, nullptr}; // behind the last collective, alternating (CHAINED)
     int chain_next = 0;
     hipStream_t chain_stream = nullptr; // the stream the last collective went to

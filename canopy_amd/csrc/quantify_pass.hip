@@ -569,7 +569,7 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
         if (P->reader_ctx == 0 || P->reader_ctx == ctx->id) { P->reader_ctx = ctx->id; P->read_hi = seq; }
         else P->reader_ctx = kManyReaders;
     }
-    if (pl.pipelined) ctx->pipe_next = (set + 1) % canopy_ctx::kLanes;
+    if (pl.pipelined) ctx->pipe_next = (set + 1) % ctx->n_lanes;
     if (pl.want_imp) { // after the timed pass: one walk over the kept rows
         double* dst = ctx->ext_importance ? ctx->ext_importance : ctx->d_importance;
         HIP_TRY(ctx, hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(m->n_events > 0 ? m->n_events : 1), ctx->stream));

@@ -65,7 +65,7 @@ class Context:
 
     def set_pipeline(self, enable):
         """Overlap the tail of a sum-only pass with the next pass's row kernel (canopy_ctx_set_pipeline; default on)."""
-        capi.check(capi.lib().canopy_ctx_set_pipeline(self._h, 1 if enable else 0), "canopy_ctx_set_pipeline", self._h)
+        capi.check(capi.lib().canopy_ctx_set_pipeline(self._h, int(enable)), "canopy_ctx_set_pipeline", self._h)
 
     def partials_device_ptr(self):
         return capi.lib().canopy_ctx_partials_device(self._h)

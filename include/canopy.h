@@ -113,6 +113,9 @@ CANOPY_API canopy_status canopy_ctx_synchronize(canopy_ctx* ctx);
  * may block in canopy_quantify_async until the pass three back has finished; passes that ask for per-row outputs,
  * keep masks or importance, all other kernel variants, and contexts with a caller-owned gather buffer
  * (canopy_ctx_set_gather_buffer) run un-pipelined on the context's stream behind whatever is still in flight.
+ * enable: 0 = off (one pass at a time on the context's stream), 1 = on with the default of three lanes, 2 .. 4 = on with that
+ * many lanes (a fourth lane buys slack for a slow cross-GPU collective in the tail of a short shard pass). The call
+ * waits for everything in flight.
  */
 CANOPY_API canopy_status canopy_ctx_set_pipeline(canopy_ctx* ctx, int32_t enable);
 
@@ -292,8 +295,9 @@ CANOPY_API canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* 
  * ticket (the pass's number on this context, never 0); the pass's final reduce also writes its record into pinned host
  * memory of the lane it ran on, so canopy_ticket_fetch is a wait for THAT lane's completion event and a memcpy -- no
  * other lane is joined, no device copy is enqueued. A lane keeps the record of its last ticketed pass only: with
- * pipelining on, a ticket stays valid until the third ticketed pipelined pass after it is enqueued (fetch in enqueue
- * order, at most three outstanding); un-pipelined passes share one lane (fetch before the next enqueue). An expired
+ * pipelining on, a ticket stays valid until as many ticketed pipelined passes as there are lanes (three by default) have
+ * been enqueued after it (fetch in enqueue order, at most that many outstanding); un-pipelined passes share one lane
+ * (fetch before the next enqueue). An expired
  * ticket gives CANOPY_ERR_STATE. canopy_ticket_done polls without blocking. With a communicator attached
  * (canopy_comm_init_rank) canopy_comm_ticket_fetch delivers the COMBINED result of the pass.
  */

@@ -304,3 +304,42 @@ def test_config4_eight_shards_of_the_full_model_through_canopy_comm(gpu_ctx, ora
     for k in range(8):
         assert int(parts[k].n_kept) == int(o_parts[k].n_kept)
         assert rel(parts[k].rare_hi + parts[k].rare_lo, o_parts[k].rare_event) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [2, 4])
+def test_lane_count_is_a_runtime_knob(gpu_ctx, lanes):
+    """canopy_ctx_set_pipeline(n): n lanes rotate, n tickets stay valid, a new probability vector per pass still reads the
+    set it was enqueued with (the ring of sets is larger than the largest rotation); records equal the serial ones."""
+    import canopy_amd
+    n, e = 1_500_000, 12_000
+    model = gpu_ctx.synthetic(SEED, n, e, 6)
+    base = canopy_amd.synthetic_probabilities(SEED, e)
+    prm = canopy_amd.default_params(cut_off=1e-9)
+    ps = [_perturbed(base, 40 + k) for k in range(2 * lanes + 3)]
+    gpu_ctx.set_pipeline(0)
+    serial = []
+    for p in ps:
+        model.set_probabilities(p)
+        serial.append(gpu_ctx.ticket_fetch(gpu_ctx.enqueue(model, prm)))
+    gpu_ctx.set_pipeline(lanes)
+    try:
+        tickets, got = [], []
+        for p in ps:
+            model.set_probabilities(p)
+            tickets.append(gpu_ctx.enqueue(model, prm))
+            if len(tickets) == lanes:
+                got.append(gpu_ctx.ticket_fetch(tickets.pop(0)))
+        while tickets:
+            got.append(gpu_ctx.ticket_fetch(tickets.pop(0)))
+        assert len(got) == len(serial) and all(_same(a, b) for a, b in zip(got, serial))
+        # exactly `lanes` tickets stay valid
+        t = [gpu_ctx.enqueue(model, prm) for _ in range(lanes + 1)]
+        from canopy_amd import _capi
+        with pytest.raises(_capi.CanopyError):
+            gpu_ctx.ticket_fetch(t[0])
+        for x in t[1:]:
+            assert _same(gpu_ctx.ticket_fetch(x), serial[-1])
+    finally:
+        gpu_ctx.set_pipeline(1)  # the default rotation
+    model.close()
