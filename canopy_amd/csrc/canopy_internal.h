@@ -214,6 +214,13 @@ struct canopy_dag {
     int32_t* d_level_ptr = nullptr;  // [n_levels+1] into the level-ordered gate list
     uint64_t* d_thresh = nullptr;    // [n_events] ceil(p * 2^53)
     bool has_p = false;
+    // second internal form (kernels_mc.hip, k_mc_reg): helper trees of fan-in 4, the top OR folded into the gates it reads
+    bool reg_ok = false, reg_top_folded = false, reg_top_out_flip = false;
+    int32_t reg_n_gates = 0, reg_n_levels = 0, reg_n_slots = 0, reg_top = -1, reg_n_args = 0;
+    int4* d_reg_desc = nullptr;
+    int32_t* d_reg_args = nullptr;
+    int32_t* d_reg_level_ptr = nullptr;
+    std::vector<int32_t> reg_level_gates; // gates per level (host copy: the launch derives the per-lane schedule from it)
 };
 
 struct FrP24Owned { // device buffers of the 24-bit stream form, owned by the model

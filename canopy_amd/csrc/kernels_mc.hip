@@ -16,8 +16,12 @@
 //            The gate descriptors are read once per tile (not once per word).
 //   hits += popcount(top words & valid-sample mask). Integer arithmetic only -> bit-exact vs the oracle.
 // Compute / RNG bound (vector ALU: 64-bit multiplies of the hash), not HBM bound: nothing is streamed.
+// Two kernels: k_mc above (any DAG that fits the LDS: descriptors and argument lists read per tile), and k_mc_reg (round 3:
+// the lane's gate schedule in registers, the events of several tiles drawn together with ticketed items, a top OR folded
+// into the gates it reads) for DAGs whose gates lower to at most four arguments -- 72 -> 45 ms per 1e9 samples at config 5.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <new>
@@ -39,6 +43,8 @@ namespace {
 constexpr uint64_t kStreamMc = 4;
 constexpr int kMcThreads = 512; // 8 waves: one pass per DAG level for a few hundred gates x W/2 word pairs
 constexpr int kMaxAtleastArgs = 63;
+constexpr int kMcRegMaxLevels = 16; // k_mc_reg: levels and per-lane schedule slots it can hold
+constexpr int kMcRegMaxSlots = 16;
 
 struct McArgs {
     const int4* desc;        // level-ordered gates: {type | K << 8, output node, arg begin, arg end}
@@ -267,6 +273,222 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(McArgs a) {
     }
 }
 
+
+// ---- k_mc_reg (round 3): the gate schedule in registers, several tiles hashed at once ----------------------------
+// Two things bound k_mc above (profiles/r01_pmc_summary_mc.txt: 22 % vector-ALU issue, 59 % of the wave cycles waiting):
+//   * phase 2 re-reads every gate's descriptor and argument list out of LDS for every tile, although a lane evaluates the
+//     SAME (gate, word pair) items tile after tile: a third of the LDS bytes and all the index arithmetic of a level are
+//     loop invariants. Here every lane loads its items ONCE -- per item four LDS byte addresses of the arguments (bit 0 =
+//     complemented), the destination address and the flag word -- into registers (the DAG is lowered to gates of at most four
+//     arguments for this kernel), and a tile's phase 2 is straight-line code: 4 x ds_read_b128, OR, ds_write_b128 per item.
+//   * phase 1 hands a lane one or two (event, word) items of ~7 hash rounds each (a geometric tail): the wave runs to its
+//     slowest lane, 57 % of the lanes busy. Here the events of T tiles are drawn together into a staging area (T x 800 items on
+//     512 lanes at config 5: six per lane), and the tiles then take their turn through the gates.
+// The top event, when it is an OR over gates (the usual shape: a tree's top), is not a gate at all here: the lanes OR the words
+// of the gates it reads as they produce them, one cross-lane reduction per tile replaces the levels of its helper tree.
+// Sample definition, node words, hit count: identical to k_mc and to the oracle, bit for bit.
+struct McPlan { // per-lane schedule: slot k = item (tid + slot_j[k] * 512) of level slot_lv[k]; the same for every lane
+    int32_t n_total;
+    uint32_t barrier_mask;           // bit k: the slot opens a new level (workgroup barrier first)
+    uint8_t slot_lv[kMcRegMaxSlots];
+    uint8_t slot_j[kMcRegMaxSlots];
+    int32_t top_folded, top_out_flip;
+    int32_t T;                       // tiles whose events are drawn together (the staging area holds T x n_events x W words)
+};
+
+struct U64x2 { uint64_t a, b; };
+
+template <int W, int NS>
+__global__ __launch_bounds__(kMcThreads) void k_mc_reg(McArgs a, McPlan plan) {
+    const int T = plan.T;
+    constexpr int WL = 2;       // words per lane in phase 2
+    constexpr int S = W / WL;   // lanes per gate
+    static_assert(W >= 2 && (kMcThreads % S) == 0, "a lane keeps the same word pair in every slot");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid / kWave;
+    const int n_nodes = a.n_slots;
+    // LDS: node[n_nodes][W] | stage[T][n_events][W] | ek[n_events] | th[n_events] | red[waves][W]
+    uint64_t* node = reinterpret_cast<uint64_t*>(smem);
+    const size_t node_bytes = ((size_t)n_nodes * W * 8 + 15) & ~(size_t)15;
+    uint64_t* stage = reinterpret_cast<uint64_t*>(smem + node_bytes);
+    uint64_t* s_ek = stage + (size_t)T * a.n_events * W;
+    uint64_t* s_th = s_ek + a.n_events;
+    uint64_t* s_red = s_th + a.n_events;
+    unsigned* s_ticket = reinterpret_cast<unsigned*>(s_red + (size_t)(kMcThreads / kWave) * W); // [W]
+    const float inv_events = 1.0f / (float)(a.n_events > 0 ? a.n_events : 1);
+    if (tid < 2 * W) node[(size_t)(a.n_slots - 2) * W + tid] = tid < W ? 0ULL : ~0ULL; // the constant FALSE / TRUE nodes
+    for (int i = tid; i < a.n_events; i += kMcThreads) {
+        s_ek[i] = mix64(a.key ^ (uint64_t)i);
+        s_th[i] = a.thresh[i];
+    }
+    // ---- the lane's schedule, once: LDS byte addresses and flags of its items
+    uint32_t sa[NS][4], sdst[NS], sflg[NS];
+    const int sub = tid % S;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        sflg[k] = 0; sdst[k] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sa[k][q] = 0;
+        if (k < plan.n_total) {
+            const int lv = plan.slot_lv[k];
+            const int g0 = a.level_ptr[lv];
+            const int n_it = (a.level_ptr[lv + 1] - g0) * S;
+            const int it = tid + (int)plan.slot_j[k] * kMcThreads;
+            if (it < n_it) {
+                const int4 d = a.desc[g0 + it / S];
+                uint32_t f = ((uint32_t)d.x << 1) | 1u; // bit 0 valid, 1..8 type, 9..16 K, 17 in_flip, 18 out_flip, 19 feeds the top
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int32_t aa = a.args[d.z + q]; // (padded to four by the lowering)
+                    const int32_t sgn = aa >> 31;
+                    sa[k][q] = (uint32_t)(((aa ^ sgn) * W + sub * WL) * 8);
+                    f |= (uint32_t)(sgn & 1) << (20 + q); // bits 20..23: argument q is complemented
+                }
+                sdst[k] = (uint32_t)((d.y * W + sub * WL) * 8);
+                sflg[k] = f;
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long my_hits = 0;
+    const int64_t n_tiles = (a.n_words + W - 1) / W;
+    const int64_t n_super = (n_tiles + T - 1) / T;
+    const int items_tile = a.n_events * W;
+    for (int64_t st = blockIdx.x; st < n_super; st += gridDim.x) {
+        const int64_t w_super = st * T * W; // first word of the super-tile
+        // ---- phase 1: the (event, word) items of T tiles, one lane resolves the 64 samples of an item plane by plane.
+        // A lane keeps ITS word of the tile (512 lanes = 64 rows of W words): item = (row, tid % W), row = t * n_events + j walks
+        // down 64 rows at a time -- no division per item. The threshold travels shifted (its next bit is the sign bit).
+        {
+            constexpr int RSTEP = kMcThreads / W;
+            const int wi = tid % W;
+            const int n_rows = T * a.n_events;
+            // rows are handed out: the first 64 by position, the rest by a ticket per word column (an item takes 1 .. 53 hash
+            // rounds, ~7 on average: lanes that draw short items come back for more instead of waiting for the wave's longest)
+            if (tid < W) s_ticket[tid] = RSTEP;
+            __syncthreads();
+            int row = tid / W, t = 0, j = 0;
+            int k = 0;
+            uint64_t ctr = 0, Tsh = 0, lt = 0, und = 0;
+            bool active = row < n_rows;
+            bool fresh = active;
+            while (__any(active)) {
+                if (active) {
+                    if (fresh) {
+                        t = (int)(((float)row + 0.5f) * inv_events); // row = t * n_events + j (row < 2^23: the float quotient is off by one at most)
+                        if (t * a.n_events > row) --t;
+                        else if ((t + 1) * a.n_events <= row) ++t;
+                        j = row - t * a.n_events;
+                        ctr = s_ek[j] + (uint64_t)(a.first_word + w_super + (int64_t)t * W + wi) * 64u;
+                        const uint64_t Tt = s_th[j];
+                        const bool certain = (Tt >> 53) != 0 || MC_ABL(1); // p == 1
+                        Tsh = Tt << 11;                                      // bit 52 of the threshold in bit 63
+                        lt = certain ? ~0ULL : 0ULL;
+                        und = certain ? 0ULL : ~0ULL;
+                        k = 0;
+                        fresh = false;
+                    }
+                    if (und != 0ULL && k < 53) {
+                        const uint64_t r = mix64(ctr + (uint64_t)k);
+                        const uint64_t tbm = (uint64_t)((int64_t)Tsh >> 63); // all ones: the threshold's bit of this plane is 1
+                        const uint64_t un = und & (r ^ ~tbm);               // still equal to the threshold's prefix
+                        lt |= (und ^ un) & tbm;                             // threshold bit 1, sample bit 0: below
+                        und = un;
+                        Tsh <<= 1;
+                        ++k;
+                    }
+                    if (und == 0ULL || k == 53) { // k == 53 with lanes left: u == threshold, not below
+                        stage[(size_t)row * W + wi] = lt; // stage[t][j][wi]
+                        row = (int)atomicAdd(&s_ticket[wi], 1u);
+                        active = row < n_rows;
+                        fresh = active;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            // the tile's event words into the node array (slot j = event j)
+            for (int i = tid; i < items_tile; i += kMcThreads) node[i] = stage[(size_t)t * items_tile + i];
+            __syncthreads();
+            uint64_t top0 = 0ULL, top1 = 0ULL;
+            // ---- phase 2: the lane's items, straight out of its registers
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (k < plan.n_total && !MC_ABL(2)) { // (uniform)
+                    if ((plan.barrier_mask >> k) & 1u) __syncthreads();
+                    uint32_t f = sflg[k];
+                    asm volatile("" : "+v"(f)); // (everything decoded from the flag word is decoded per tile: hoisted out of the tile loop
+                                                //  the masks of 8 x 4 arguments alone would take 64 registers)
+                    if (f & 1u) {
+                        const uint32_t fin = 0u - ((f >> 17) & 1u), fout = 0u - ((f >> 18) & 1u);
+                        const uint64_t out_flip = ((uint64_t)fout << 32) | fout;
+                        uint64_t x0[4], x1[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const U64x2 v = *reinterpret_cast<const U64x2*>(smem + sa[k][q]);
+                            const uint32_t mq = (0u - ((f >> (20 + q)) & 1u)) ^ fin;
+                            const uint64_t m = ((uint64_t)mq << 32) | mq;
+                            x0[q] = v.a ^ m; x1[q] = v.b ^ m;
+                        }
+                        uint64_t r0 = ((x0[0] | x0[1]) | (x0[2] | x0[3])) ^ out_flip;
+                        uint64_t r1 = ((x1[0] | x1[1]) | (x1[2] | x1[3])) ^ out_flip;
+                        const int type = (int)((f >> 1) & 0xffu);
+                        const bool vote = type == CANOPY_GATE_ATLEAST, is_xor = type == CANOPY_GATE_XOR;
+                        if (__any(vote || is_xor)) { // (the K-of-N gates sort last inside a level: most waves never come here)
+                            if (is_xor) { r0 = (x0[0] ^ x0[1]) ^ (x0[2] ^ x0[3]); r1 = (x1[0] ^ x1[1]) ^ (x1[2] ^ x1[3]); }
+                            if (vote) {
+                                const int K = (int)((f >> 9) & 0xffu);
+                                uint64_t c0[6] = {0, 0, 0, 0, 0, 0}, c1[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) { vote_add<3>(c0, x0[q]); vote_add<3>(c1, x1[q]); }
+                                r0 = vote_ge<3>(c0, K); r1 = vote_ge<3>(c1, K);
+                            }
+                        }
+                        U64x2 o; o.a = r0; o.b = r1;
+                        *reinterpret_cast<U64x2*>(smem + sdst[k]) = o;
+                        if (f & (1u << 19)) { top0 |= r0; top1 |= r1; } // this gate is an argument of the (folded) top OR
+                    }
+                }
+            }
+            // ---- the top event's words of this tile
+            const int64_t w0 = w_super + (int64_t)t * W;
+            if (plan.top_folded) {
+#pragma unroll
+                for (int dlt = S; dlt < kWave; dlt <<= 1) { // lanes of equal tid % S hold the same word pair
+                    top0 |= __shfl_xor(top0, dlt, kWave);
+                    top1 |= __shfl_xor(top1, dlt, kWave);
+                }
+                if (lane < S) { s_red[wave * W + lane * WL] = top0; s_red[wave * W + lane * WL + 1] = top1; }
+                __syncthreads();
+                if (tid < W) {
+                    uint64_t v = 0ULL;
+#pragma unroll
+                    for (int wv = 0; wv < kMcThreads / kWave; ++wv) v |= s_red[wv * W + tid];
+                    if (plan.top_out_flip) v = ~v;
+                    const int64_t left = a.num_trials - (w0 + tid) * 64;
+                    if (left > 0) my_hits += (unsigned long long)__builtin_popcountll(v & (left >= 64 ? ~0ULL : ((1ULL << left) - 1ULL)));
+                }
+            } else {
+                __syncthreads();
+                if (tid < W) {
+                    const int64_t left = a.num_trials - (w0 + tid) * 64;
+                    if (left > 0)
+                        my_hits += (unsigned long long)__builtin_popcountll(node[(size_t)a.top * W + tid] & (left >= 64 ? ~0ULL : ((1ULL << left) - 1ULL)));
+                }
+            }
+            __syncthreads(); // the next tile overwrites the event slots (and s_red)
+        }
+    }
+    if (tid < kWave) { // only the first wave counted (W <= 64)
+#pragma unroll
+        for (int dlt = kWave / 2; dlt >= 1; dlt >>= 1) my_hits += __shfl_down(my_hits, dlt, kWave);
+        if (lane == 0 && my_hits) atomicAdd(a.hits, my_hits); // integer: order-independent
+    }
+}
+
 #define HIP_TRY(ctx, expr)                                                                              \
     do {                                                                                                \
         hipError_t _e = (expr);                                                                         \
@@ -280,9 +502,164 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(McArgs a) {
 void free_dag(canopy_dag* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
-    void* ptrs[] = {d->d_desc, d->d_args, d->d_level_ptr, d->d_thresh};
+    void* ptrs[] = {d->d_desc, d->d_args, d->d_level_ptr, d->d_thresh, d->d_reg_desc, d->d_reg_args, d->d_reg_level_ptr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete d;
+}
+
+// The internal form of a gate DAG the kernels evaluate (host side, at upload).
+struct Lowered {
+    std::vector<int32_t> desc, args, level_ptr; // desc: 4 ints per gate {type | K << 8 | flags, output slot, arg begin, arg end}
+    int32_t n_gates = 0, n_levels = 0, n_slots = 0, top_slot = -1, vote_planes = 6, max_args = 0;
+    bool top_folded = false, top_out_flip = false;
+};
+
+// max_fan_in: AND / OR / XOR family gates with more arguments become trees of helper gates of at most that many.
+// fold_top: when the top event is an OR / NOR gate over un-complemented gates that nothing else reads, it is NOT emitted:
+// the gates it reads carry the flag bit 18 ("feeds the top") and the kernel ORs their words as it produces them.
+void lower_dag(const canopy_dag_view* v, int32_t kMaxFanIn, bool fold_top, Lowered& L) {
+    bool fold = false;
+    int32_t top_gate = -1;
+    if (fold_top && v->top >= v->n_events) {
+        top_gate = v->top - v->n_events;
+        const int32_t tt = v->gate_type[top_gate];
+        fold = tt == CANOPY_GATE_OR || tt == CANOPY_GATE_NOR;
+        for (int32_t k = v->arg_ptr[top_gate]; fold && k < v->arg_ptr[top_gate + 1]; ++k)
+            if (v->args[k] < v->n_events) fold = false; // an event or a complemented argument
+        for (int32_t g = 0; fold && g < v->n_gates; ++g)
+            for (int32_t k = v->arg_ptr[g]; k < v->arg_ptr[g + 1]; ++k) {
+                const int32_t raw = v->args[k];
+                if ((raw >= 0 ? raw : ~raw) == v->top) { fold = false; break; } // somebody reads the top gate
+            }
+        if (fold) { L.top_folded = true; L.top_out_flip = tt == CANOPY_GATE_NOR; }
+    }
+    std::vector<char> feeds_top_ext((size_t)v->n_gates, 0);
+    if (fold)
+        for (int32_t k = v->arg_ptr[top_gate]; k < v->arg_ptr[top_gate + 1]; ++k) feeds_top_ext[(size_t)(v->args[k] - v->n_events)] = 1;
+    // Internal gate list. A lane evaluates one gate by walking its arguments one after the other, so a wide
+    // gate (the OR over a whole layer at the top of a tree) would serialise hundreds of dependent LDS reads
+    // in a single lane while the rest of the workgroup waits at the level barrier. AND / OR / XOR are
+    // associative: gates of those families with more than kMaxFanIn arguments become a tree of helper gates
+    // of at most kMaxFanIn arguments (NAND / NOR: helpers of the AND / OR family, negation at the root).
+    // Same Boolean function, so the same sample bits; node ids are internal from here on.
+    struct IGate { int32_t type, K; std::vector<int32_t> args; bool feeds_top; };
+    std::vector<IGate> ig;
+    ig.reserve((size_t)v->n_gates + 16);
+    std::vector<int32_t> node_of((size_t)v->n_gates, 0); // external gate -> internal node id
+    auto map_arg = [&](int32_t raw) {
+        const int32_t id = raw >= 0 ? raw : ~raw;
+        const int32_t m = id < v->n_events ? id : node_of[(size_t)(id - v->n_events)];
+        return raw >= 0 ? m : ~m;
+    };
+    for (int32_t g = 0; g < v->n_gates; ++g) {
+        if (fold && g == top_gate) continue; // folded into the gates it reads
+        const int32_t type = v->gate_type[g];
+        std::vector<int32_t> cur;
+        for (int32_t k = v->arg_ptr[g]; k < v->arg_ptr[g + 1]; ++k) cur.push_back(map_arg(v->args[k]));
+        const bool assoc = type == CANOPY_GATE_AND || type == CANOPY_GATE_OR || type == CANOPY_GATE_XOR ||
+                           type == CANOPY_GATE_NAND || type == CANOPY_GATE_NOR;
+        if (assoc) {
+            const int32_t base = type == CANOPY_GATE_NAND ? (int32_t)CANOPY_GATE_AND
+                                 : type == CANOPY_GATE_NOR ? (int32_t)CANOPY_GATE_OR : type;
+            while ((int32_t)cur.size() > kMaxFanIn) {
+                std::vector<int32_t> next;
+                for (size_t c0 = 0; c0 < cur.size(); c0 += kMaxFanIn) {
+                    const size_t c1 = std::min(cur.size(), c0 + (size_t)kMaxFanIn);
+                    if (c1 - c0 == 1) { next.push_back(cur[c0]); continue; }
+                    ig.push_back({base, 0, std::vector<int32_t>(cur.begin() + (long)c0, cur.begin() + (long)c1), false});
+                    next.push_back(v->n_events + (int32_t)ig.size() - 1);
+                }
+                cur.swap(next);
+            }
+        }
+        ig.push_back({type, (type == CANOPY_GATE_ATLEAST && v->gate_min) ? v->gate_min[g] : 0, cur, feeds_top_ext[(size_t)g] != 0});
+        node_of[(size_t)g] = v->n_events + (int32_t)ig.size() - 1;
+    }
+    const int32_t n_igates = (int32_t)ig.size();
+    int32_t max_vote_args = 0;
+    for (const IGate& q : ig)
+        if (q.type == CANOPY_GATE_ATLEAST) max_vote_args = std::max(max_vote_args, (int32_t)q.args.size());
+    const int32_t top_node = fold ? -1 : (v->top < v->n_events ? v->top : node_of[(size_t)(v->top - v->n_events)]);
+    std::vector<int32_t> level((size_t)n_igates, 0);
+    int32_t n_levels = 0;
+    for (int32_t g = 0; g < n_igates; ++g) {
+        int32_t lv = 0;
+        for (int32_t raw : ig[(size_t)g].args) {
+            const int32_t id = raw >= 0 ? raw : ~raw;
+            if (id >= v->n_events) lv = std::max(lv, level[(size_t)(id - v->n_events)] + 1);
+        }
+        level[(size_t)g] = lv;
+        n_levels = std::max(n_levels, lv + 1);
+    }
+    // level-ordered gate list (stable inside a level)
+    std::vector<int32_t> order((size_t)n_igates);
+    for (int32_t g = 0; g < n_igates; ++g) order[(size_t)g] = g;
+    // inside a level the K-of-N gates go last, so that most waves never run the vote counter
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        if (level[(size_t)x] != level[(size_t)y]) return level[(size_t)x] < level[(size_t)y];
+        return (ig[(size_t)x].type == CANOPY_GATE_ATLEAST) < (ig[(size_t)y].type == CANOPY_GATE_ATLEAST);
+    });
+    std::vector<int32_t> l_desc, l_args, level_ptr((size_t)n_levels + 1, 0);
+    // LDS slots by liveness: a node's slot is recycled after the last level that reads it (the top node's
+    // never), so a layered tree keeps its events plus about two layers resident instead of every gate --
+    // which is what lets a tile hold twice as many sample words. A slot released after level L is handed out
+    // at level L + 1 at the earliest: no gate of that level reads it, so writing it there is safe.
+    const int32_t n_inodes = v->n_events + n_igates;
+    std::vector<int32_t> last_use((size_t)n_inodes, -1), slot_of((size_t)n_inodes, -1);
+    for (int32_t g = 0; g < n_igates; ++g)
+        for (int32_t raw : ig[(size_t)g].args) {
+            const int32_t id = raw >= 0 ? raw : ~raw;
+            last_use[(size_t)id] = std::max(last_use[(size_t)id], level[(size_t)g]);
+        }
+    for (int32_t g = 0; g < n_igates; ++g) // a gate's slot lives at least through its own level
+        last_use[(size_t)(v->n_events + g)] = std::max(last_use[(size_t)(v->n_events + g)], level[(size_t)g]);
+    if (top_node >= 0) last_use[(size_t)top_node] = n_levels + 1; // read after the last level
+    std::vector<std::vector<int32_t>> released((size_t)n_levels + 2);
+    for (int32_t id = 0; id < n_inodes; ++id) {
+        const int32_t lu = last_use[(size_t)id];
+        if (lu <= n_levels) released[(size_t)(lu < 0 ? 0 : lu + 1)].push_back(id); // free from level lu + 1 on
+    }
+    for (int32_t j = 0; j < v->n_events; ++j) slot_of[(size_t)j] = j; // phase 1 writes event j to slot j
+    int32_t n_slots = v->n_events;
+    {
+        std::vector<int32_t> free_slots; // kept sorted descending: pop_back() = smallest slot
+        size_t oi = 0;
+        for (int32_t lv = 0; lv < n_levels; ++lv) {
+            for (int32_t id : released[(size_t)lv])
+                if (slot_of[(size_t)id] >= 0) free_slots.push_back(slot_of[(size_t)id]);
+            std::sort(free_slots.begin(), free_slots.end(), [](int32_t x, int32_t y) { return x > y; });
+            for (; oi < order.size() && level[(size_t)order[oi]] == lv; ++oi) {
+                int32_t sl;
+                if (!free_slots.empty()) { sl = free_slots.back(); free_slots.pop_back(); }
+                else sl = n_slots++;
+                slot_of[(size_t)(v->n_events + order[oi])] = sl;
+            }
+        }
+    }
+    auto slot_arg = [&](int32_t raw) { return raw >= 0 ? slot_of[(size_t)raw] : ~slot_of[(size_t)~raw]; };
+    const int32_t false_node = n_slots, true_node = n_slots + 1; // constants kept by the kernel
+    for (int32_t g : order) {
+        const int32_t b = (int32_t)l_args.size();
+        const int32_t type = ig[(size_t)g].type;
+        // AND family: arguments are complemented on the way in (in_flip), so its neutral padding is TRUE
+        const bool in_flip = type == CANOPY_GATE_AND || type == CANOPY_GATE_NAND;
+        const bool out_flip = type == CANOPY_GATE_AND || type == CANOPY_GATE_NOR || type == CANOPY_GATE_NOT;
+        for (int32_t x : ig[(size_t)g].args) l_args.push_back(slot_arg(x));
+        while ((l_args.size() - (size_t)b) % 4 != 0) l_args.push_back(in_flip ? true_node : false_node);
+        l_desc.push_back(type | (ig[(size_t)g].K << 8) | ((int32_t)in_flip << 16) | ((int32_t)out_flip << 17) |
+                         ((int32_t)ig[(size_t)g].feeds_top << 18));
+        L.max_args = std::max(L.max_args, (int32_t)ig[(size_t)g].args.size());
+        l_desc.push_back(slot_of[(size_t)(v->n_events + g)]);
+        l_desc.push_back(b);
+        l_desc.push_back((int32_t)l_args.size());
+        level_ptr[(size_t)level[(size_t)g] + 1] += 1;
+    }
+    for (int32_t l = 0; l < n_levels; ++l) level_ptr[(size_t)l + 1] += level_ptr[(size_t)l];
+
+    L.desc.swap(l_desc); L.args.swap(l_args); L.level_ptr.swap(level_ptr);
+    L.n_gates = n_igates; L.n_levels = n_levels; L.n_slots = n_slots + 2; // + constant FALSE / TRUE
+    L.top_slot = top_node >= 0 ? slot_of[(size_t)top_node] : -1;
+    L.vote_planes = max_vote_args <= 7 ? 3 : 6;
 }
 
 } // namespace
@@ -319,141 +696,38 @@ canopy_status canopy_dag_upload(canopy_ctx* ctx, const canopy_dag_view* v, canop
                 return fail(ctx, CANOPY_ERR_INVALID_MODEL, "gate " + std::to_string(g) + ": argument is not an earlier node");
         }
     }
-    // Internal gate list. A lane evaluates one gate by walking its arguments one after the other, so a wide
-    // gate (the OR over a whole layer at the top of a tree) would serialise hundreds of dependent LDS reads
-    // in a single lane while the rest of the workgroup waits at the level barrier. AND / OR / XOR are
-    // associative: gates of those families with more than kMaxFanIn arguments become a tree of helper gates
-    // of at most kMaxFanIn arguments (NAND / NOR: helpers of the AND / OR family, negation at the root).
-    // Same Boolean function, so the same sample bits; node ids are internal from here on.
-    constexpr int32_t kMaxFanIn = 8;
-    struct IGate { int32_t type, K; std::vector<int32_t> args; };
-    std::vector<IGate> ig;
-    ig.reserve((size_t)v->n_gates + 16);
-    std::vector<int32_t> node_of((size_t)v->n_gates, 0); // external gate -> internal node id
-    auto map_arg = [&](int32_t raw) {
-        const int32_t id = raw >= 0 ? raw : ~raw;
-        const int32_t m = id < v->n_events ? id : node_of[(size_t)(id - v->n_events)];
-        return raw >= 0 ? m : ~m;
-    };
-    for (int32_t g = 0; g < v->n_gates; ++g) {
-        const int32_t type = v->gate_type[g];
-        std::vector<int32_t> cur;
-        for (int32_t k = v->arg_ptr[g]; k < v->arg_ptr[g + 1]; ++k) cur.push_back(map_arg(v->args[k]));
-        const bool assoc = type == CANOPY_GATE_AND || type == CANOPY_GATE_OR || type == CANOPY_GATE_XOR ||
-                           type == CANOPY_GATE_NAND || type == CANOPY_GATE_NOR;
-        if (assoc) {
-            const int32_t base = type == CANOPY_GATE_NAND ? (int32_t)CANOPY_GATE_AND
-                                 : type == CANOPY_GATE_NOR ? (int32_t)CANOPY_GATE_OR : type;
-            while ((int32_t)cur.size() > kMaxFanIn) {
-                std::vector<int32_t> next;
-                for (size_t c0 = 0; c0 < cur.size(); c0 += kMaxFanIn) {
-                    const size_t c1 = std::min(cur.size(), c0 + (size_t)kMaxFanIn);
-                    if (c1 - c0 == 1) { next.push_back(cur[c0]); continue; }
-                    ig.push_back({base, 0, std::vector<int32_t>(cur.begin() + (long)c0, cur.begin() + (long)c1)});
-                    next.push_back(v->n_events + (int32_t)ig.size() - 1);
-                }
-                cur.swap(next);
-            }
-        }
-        ig.push_back({type, (type == CANOPY_GATE_ATLEAST && v->gate_min) ? v->gate_min[g] : 0, cur});
-        node_of[(size_t)g] = v->n_events + (int32_t)ig.size() - 1;
-    }
-    const int32_t n_igates = (int32_t)ig.size();
-    int32_t max_vote_args = 0;
-    for (const IGate& q : ig)
-        if (q.type == CANOPY_GATE_ATLEAST) max_vote_args = std::max(max_vote_args, (int32_t)q.args.size());
-    const int32_t top_node = v->top < v->n_events ? v->top : node_of[(size_t)(v->top - v->n_events)];
-    std::vector<int32_t> level((size_t)n_igates, 0);
-    int32_t n_levels = 0;
-    for (int32_t g = 0; g < n_igates; ++g) {
-        int32_t lv = 0;
-        for (int32_t raw : ig[(size_t)g].args) {
-            const int32_t id = raw >= 0 ? raw : ~raw;
-            if (id >= v->n_events) lv = std::max(lv, level[(size_t)(id - v->n_events)] + 1);
-        }
-        level[(size_t)g] = lv;
-        n_levels = std::max(n_levels, lv + 1);
-    }
-    // level-ordered gate list (stable inside a level)
-    std::vector<int32_t> order((size_t)n_igates);
-    for (int32_t g = 0; g < n_igates; ++g) order[(size_t)g] = g;
-    // inside a level the K-of-N gates go last, so that most waves never run the vote counter
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-        if (level[(size_t)x] != level[(size_t)y]) return level[(size_t)x] < level[(size_t)y];
-        return (ig[(size_t)x].type == CANOPY_GATE_ATLEAST) < (ig[(size_t)y].type == CANOPY_GATE_ATLEAST);
-    });
-    std::vector<int32_t> l_desc, l_args, level_ptr((size_t)n_levels + 1, 0);
-    // LDS slots by liveness: a node's slot is recycled after the last level that reads it (the top node's
-    // never), so a layered tree keeps its events plus about two layers resident instead of every gate --
-    // which is what lets a tile hold twice as many sample words. A slot released after level L is handed out
-    // at level L + 1 at the earliest: no gate of that level reads it, so writing it there is safe.
-    const int32_t n_inodes = v->n_events + n_igates;
-    std::vector<int32_t> last_use((size_t)n_inodes, -1), slot_of((size_t)n_inodes, -1);
-    for (int32_t g = 0; g < n_igates; ++g)
-        for (int32_t raw : ig[(size_t)g].args) {
-            const int32_t id = raw >= 0 ? raw : ~raw;
-            last_use[(size_t)id] = std::max(last_use[(size_t)id], level[(size_t)g]);
-        }
-    for (int32_t g = 0; g < n_igates; ++g) // a gate's slot lives at least through its own level
-        last_use[(size_t)(v->n_events + g)] = std::max(last_use[(size_t)(v->n_events + g)], level[(size_t)g]);
-    last_use[(size_t)top_node] = n_levels + 1; // read after the last level
-    std::vector<std::vector<int32_t>> released((size_t)n_levels + 2);
-    for (int32_t id = 0; id < n_inodes; ++id) {
-        const int32_t lu = last_use[(size_t)id];
-        if (lu <= n_levels) released[(size_t)(lu < 0 ? 0 : lu + 1)].push_back(id); // free from level lu + 1 on
-    }
-    for (int32_t j = 0; j < v->n_events; ++j) slot_of[(size_t)j] = j; // phase 1 writes event j to slot j
-    int32_t n_slots = v->n_events;
-    {
-        std::vector<int32_t> free_slots; // kept sorted descending: pop_back() = smallest slot
-        size_t oi = 0;
-        for (int32_t lv = 0; lv < n_levels; ++lv) {
-            for (int32_t id : released[(size_t)lv])
-                if (slot_of[(size_t)id] >= 0) free_slots.push_back(slot_of[(size_t)id]);
-            std::sort(free_slots.begin(), free_slots.end(), [](int32_t x, int32_t y) { return x > y; });
-            for (; oi < order.size() && level[(size_t)order[oi]] == lv; ++oi) {
-                int32_t sl;
-                if (!free_slots.empty()) { sl = free_slots.back(); free_slots.pop_back(); }
-                else sl = n_slots++;
-                slot_of[(size_t)(v->n_events + order[oi])] = sl;
-            }
-        }
-    }
-    auto slot_arg = [&](int32_t raw) { return raw >= 0 ? slot_of[(size_t)raw] : ~slot_of[(size_t)~raw]; };
-    const int32_t false_node = n_slots, true_node = n_slots + 1; // constants kept by the kernel
-    for (int32_t g : order) {
-        const int32_t b = (int32_t)l_args.size();
-        const int32_t type = ig[(size_t)g].type;
-        // AND family: arguments are complemented on the way in (in_flip), so its neutral padding is TRUE
-        const bool in_flip = type == CANOPY_GATE_AND || type == CANOPY_GATE_NAND;
-        const bool out_flip = type == CANOPY_GATE_AND || type == CANOPY_GATE_NOR || type == CANOPY_GATE_NOT;
-        for (int32_t x : ig[(size_t)g].args) l_args.push_back(slot_arg(x));
-        while ((l_args.size() - (size_t)b) % 4 != 0) l_args.push_back(in_flip ? true_node : false_node);
-        l_desc.push_back(type | (ig[(size_t)g].K << 8) | ((int32_t)in_flip << 16) | ((int32_t)out_flip << 17));
-        l_desc.push_back(slot_of[(size_t)(v->n_events + g)]);
-        l_desc.push_back(b);
-        l_desc.push_back((int32_t)l_args.size());
-        level_ptr[(size_t)level[(size_t)g] + 1] += 1;
-    }
-    for (int32_t l = 0; l < n_levels; ++l) level_ptr[(size_t)l + 1] += level_ptr[(size_t)l];
-
+    Lowered L;
+    lower_dag(v, 8, false, L);
+    Lowered R; // the register-schedule kernel: gates of at most four arguments, the top OR folded
+    lower_dag(v, 4, true, R);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     canopy_dag* d = new (std::nothrow) canopy_dag();
     if (!d) return CANOPY_ERR_OUT_OF_MEMORY;
     d->device = ctx->device;
-    d->n_events = v->n_events; d->n_gates = n_igates; d->n_levels = n_levels; d->top = slot_of[(size_t)top_node];
-    d->n_slots = n_slots + 2; // + constant FALSE / TRUE
-    d->n_args = (int32_t)l_args.size();
-    d->vote_planes = max_vote_args <= 7 ? 3 : 6;
+    d->n_events = v->n_events; d->n_gates = L.n_gates; d->n_levels = L.n_levels; d->top = L.top_slot;
+    d->n_slots = L.n_slots;
+    d->n_args = (int32_t)L.args.size();
+    d->vote_planes = L.vote_planes;
+    // the second form, for k_mc_reg: usable when no gate is left with more than four arguments (a wide K-of-N gate is not
+    // associative: it stays whole, and the model runs through the generic kernel)
+    d->reg_ok = R.max_args <= 4 && R.n_levels <= kMcRegMaxLevels && R.n_gates > 0;
+    d->reg_n_gates = R.n_gates; d->reg_n_levels = R.n_levels; d->reg_n_slots = R.n_slots; d->reg_top = R.top_slot;
+    d->reg_n_args = (int32_t)R.args.size();
+    d->reg_top_folded = R.top_folded; d->reg_top_out_flip = R.top_out_flip;
+    d->reg_level_gates.clear();
+    for (int32_t l = 0; l < R.n_levels; ++l) d->reg_level_gates.push_back(R.level_ptr[(size_t)l + 1] - R.level_ptr[(size_t)l]);
     auto up = [&](int32_t** dst, const std::vector<int32_t>& src) -> hipError_t {
         hipError_t e = hipMalloc(dst, sizeof(int32_t) * std::max<size_t>(src.size(), 1));
         if (e == hipSuccess && !src.empty())
             e = hipMemcpy(*dst, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice);
         return e;
     };
-    hipError_t e = up(reinterpret_cast<int32_t**>(&d->d_desc), l_desc);
-    if (e == hipSuccess) e = up(&d->d_args, l_args);
-    if (e == hipSuccess) e = up(&d->d_level_ptr, level_ptr);
+    hipError_t e = up(reinterpret_cast<int32_t**>(&d->d_desc), L.desc);
+    if (e == hipSuccess) e = up(&d->d_args, L.args);
+    if (e == hipSuccess) e = up(&d->d_level_ptr, L.level_ptr);
+    if (e == hipSuccess && d->reg_ok) e = up(reinterpret_cast<int32_t**>(&d->d_reg_desc), R.desc);
+    if (e == hipSuccess && d->reg_ok) e = up(&d->d_reg_args, R.args);
+    if (e == hipSuccess && d->reg_ok) e = up(&d->d_reg_level_ptr, R.level_ptr);
     if (e == hipSuccess) e = hipMalloc(&d->d_thresh, sizeof(uint64_t) * (size_t)std::max(v->n_events, 1));
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -551,6 +825,67 @@ canopy_status canopy_mc_run_async(canopy_ctx* ctx, const canopy_dag* d, const ca
     if (grid < 1) grid = 1;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_mc_hits, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_mc[0], ctx->stream));
+    // ---- k_mc_reg when the model fits it: W = 8, at most 16 schedule slots per lane, two workgroups per CU
+    static const bool reg_off = CANOPY_TUNE_ENV("CANOPY_MC_NOREG") != nullptr; // tuning only
+    if (d->reg_ok && !reg_off) {
+        constexpr int RW = 8, RS = RW / 2;
+        McPlan plan;
+        memset(&plan, 0, sizeof(plan));
+        int n_total = 0;
+        bool fits = true;
+        for (int32_t lv = 0; lv < d->reg_n_levels && fits; ++lv) {
+            const int items = d->reg_level_gates[(size_t)lv] * RS;
+            const int spl = (items + kMcThreads - 1) / kMcThreads;
+            for (int j = 0; j < spl; ++j) {
+                if (n_total >= kMcRegMaxSlots) { fits = false; break; }
+                plan.slot_lv[n_total] = (uint8_t)lv;
+                plan.slot_j[n_total] = (uint8_t)j;
+                if (j == 0 && lv > 0) plan.barrier_mask |= 1u << n_total;
+                ++n_total;
+            }
+        }
+        plan.n_total = n_total;
+        plan.top_folded = d->reg_top_folded ? 1 : 0;
+        plan.top_out_flip = d->reg_top_out_flip ? 1 : 0;
+        const size_t fixed = (((size_t)d->reg_n_slots * RW * 8 + 15) & ~(size_t)15) + (size_t)d->n_events * 16 + (size_t)(kMcThreads / kWave) * RW * 8 + RW * 4 + 16;
+        const size_t per_tile = (size_t)d->n_events * RW * 8;
+        static const int t_env = CANOPY_TUNE_ENV("CANOPY_MC_T") ? atoi(CANOPY_TUNE_ENV("CANOPY_MC_T")) : 0; // tuning only
+        int Tt = 0;
+        for (int tt = 8; tt >= 1 && !Tt; --tt)
+            if (fixed + per_tile * (size_t)tt <= (size_t)78 * 1024) Tt = tt; // two workgroups per CU
+        if (!Tt && fixed + per_tile <= (size_t)156 * 1024) Tt = 1;           // one
+        if (t_env >= 1 && t_env <= 16 && fixed + per_tile * (size_t)t_env <= (size_t)156 * 1024) Tt = t_env;
+        plan.T = Tt;
+        if (fits && Tt && n_total > 0) {
+            McArgs ra = a;
+            ra.desc = d->d_reg_desc; ra.args = d->d_reg_args; ra.level_ptr = d->d_reg_level_ptr;
+            ra.n_gates = d->reg_n_gates; ra.n_levels = d->reg_n_levels; ra.top = d->reg_top; ra.n_args = d->reg_n_args; ra.n_slots = d->reg_n_slots;
+            ra.n_words = (total + 63) / 64;
+            const size_t rlds = fixed + per_tile * (size_t)Tt;
+            const int64_t r_tiles = (ra.n_words + RW - 1) / RW;
+            const int64_t r_super = (r_tiles + Tt - 1) / Tt;
+            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(2, (int64_t)((160 * 1024) / rlds)));
+            int64_t rgrid = std::min<int64_t>(r_super, (int64_t)ctx->n_cu * per_cu);
+            if (rgrid < 1) rgrid = 1;
+#define MCR_GO(NSS)                                                                                                        \
+            do {                                                                                                           \
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mc_reg<RW, NSS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                hipLaunchKernelGGL((k_mc_reg<RW, NSS>), dim3((unsigned)rgrid), dim3(kMcThreads), rlds, ctx->stream, ra, plan); \
+            } while (0)
+            if (n_total <= 8) MCR_GO(8);
+            else if (n_total <= 12) MCR_GO(12);
+            else MCR_GO(16);
+#undef MCR_GO
+            HIP_TRY(ctx, hipGetLastError());
+            if (ctx->comm) { // shards of the sample range add: one u64 sum all-reduce of {hits, trials}
+                canopy_status cst = comm_all_reduce_mc(ctx, ctx->d_mc_hits, (long long)total);
+                if (cst != CANOPY_OK) return cst;
+            }
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_mc[1], ctx->stream));
+            ctx->mc_last_trials = total;
+            return CANOPY_OK;
+        }
+    }
 // (the LDS attribute is per device: set on every launch, no process-wide flag)
 #define MC_GO(WW, LL)                                                                                                      \
     do {                                                                                                                   \

@@ -168,3 +168,88 @@ def test_gpu_mc_rejects_bad_dags(gpu_ctx):
         ok.run(1, 100)
     assert e.value.status == c.ERR_STATE
     ok.close()
+
+
+def _random_dag(rng, n_events, n_gates, max_fan, top_kind):
+    """A random gate DAG over every connective; top_kind picks the shape of the top event (what decides which kernel runs
+    and whether its top OR is folded into the gates it reads)."""
+    from canopy_amd import _capi as c
+    types = [c.GATE_AND, c.GATE_OR, c.GATE_ATLEAST, c.GATE_XOR, c.GATE_NOT, c.GATE_NAND, c.GATE_NOR, c.GATE_NULL]
+    gate_type, gate_min, arg_ptr, args = [], [], [0], []
+    for g in range(n_gates):
+        t = int(rng.choice(types, p=[0.25, 0.25, 0.15, 0.08, 0.07, 0.08, 0.07, 0.05]))
+        pool = n_events + g
+        k = 1 if t in (c.GATE_NOT, c.GATE_NULL) else int(rng.integers(2 if pool >= 2 else 1, min(max_fan, pool) + 1))
+        a = rng.choice(pool, size=min(k, pool), replace=False)
+        neg = rng.random(len(a)) < 0.2
+        gate_type.append(t)
+        gate_min.append(int(rng.integers(1, len(a) + 1)) if t == c.GATE_ATLEAST else 0)
+        args.extend(int(~x) if n else int(x) for x, n in zip(a, neg))
+        arg_ptr.append(len(args))
+    top = n_events + n_gates
+    last = list(range(n_events + max(0, n_gates - 40), n_events + n_gates))
+    if top_kind == "or_of_gates":      # folded
+        gate_type.append(c.GATE_OR); args.extend(last)
+    elif top_kind == "nor_of_gates":   # folded, output complemented
+        gate_type.append(c.GATE_NOR); args.extend(last)
+    elif top_kind == "or_with_event":  # an event among the arguments: not folded
+        gate_type.append(c.GATE_OR); args.extend(last + [0])
+    elif top_kind == "or_complemented":  # a complemented argument: not folded
+        gate_type.append(c.GATE_OR); args.extend(last[:-1] + [~last[-1]])
+    elif top_kind == "and_of_gates":   # not an OR: not folded
+        gate_type.append(c.GATE_AND); args.extend(last[:6])
+    elif top_kind == "wide_vote":      # a K-of-N gate over 30 arguments is not associative: the generic kernel runs
+        gate_type.append(c.GATE_ATLEAST); args.extend(last[:30])
+    gate_min.append(3 if top_kind == "wide_vote" else 0)
+    arg_ptr.append(len(args))
+    return dict(n_events=n_events, gate_type=np.array(gate_type, dtype=np.int32), gate_min=np.array(gate_min, dtype=np.int32),
+                arg_ptr=np.array(arg_ptr, dtype=np.int32), args=np.array(args, dtype=np.int32), top=top)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("top_kind", ["or_of_gates", "nor_of_gates", "or_with_event", "or_complemented", "and_of_gates", "wide_vote"])
+def test_gpu_mc_both_kernels_every_top_shape(gpu_ctx, oracle, top_kind):
+    """The register-schedule kernel (gates lowered to <= 4 arguments, a top OR over gates folded into the gates it reads)
+    and the generic one (anything else) against the oracle, bit for bit, over random DAGs of every connective -- 3 sizes
+    (a handful of gates; a few levels; more items than one schedule slot per lane per level)."""
+    from canopy_amd.quantifier import Dag
+    for seed, (n_events, n_gates, max_fan) in enumerate([(5, 8, 4), (40, 300, 6), (120, 1500, 9)]):
+        rng = np.random.default_rng(700 + seed)
+        dag = _random_dag(rng, n_events, n_gates, max_fan, top_kind)
+        p = rng.uniform(0.02, 0.6, n_events)
+        p[0] = 1.0  # a certain event
+        if n_events > 3:
+            p[3] = 0.0
+        d = Dag(gpu_ctx, dag)
+        d.set_probabilities(p)
+        for n, first in ((64 * 3 + 5, 0), (200_000, 128), (64 * 8 * 6 * 3, 0)):
+            got = d.run(SEED + seed, n, first_sample=first)
+            want = oracle.mc(dag, p, SEED + seed, n, first_sample=first, n_threads=8)
+            assert got.hits == want, (top_kind, n_events, n_gates, n, first, got.hits, want)
+        d.close()
+
+
+@pytest.mark.gpu
+def test_gpu_mc_deep_chain_and_batch_sample_multipliers(gpu_ctx, oracle):
+    """A chain of 40 two-input gates has more levels than the register schedule holds (generic kernel); and the reference's
+    batch_size / sample_size knobs (settings.h:326-327) multiply the samples of a call."""
+    from canopy_amd import _capi as c
+    from canopy_amd.quantifier import Dag
+    n_events = 6
+    gate_type, gate_min, arg_ptr, args = [], [], [0], []
+    for g in range(40):
+        gate_type.append(c.GATE_OR if g % 2 == 0 else c.GATE_AND)
+        gate_min.append(0)
+        prev = n_events + g - 1 if g > 0 else 0
+        args.extend([prev, (g + 1) % n_events])
+        arg_ptr.append(len(args))
+    dag = dict(n_events=n_events, gate_type=np.array(gate_type, dtype=np.int32), gate_min=np.array(gate_min, dtype=np.int32),
+               arg_ptr=np.array(arg_ptr, dtype=np.int32), args=np.array(args, dtype=np.int32), top=n_events + 39)
+    p = np.array([0.3, 0.5, 0.7, 0.2, 0.9, 0.4])
+    d = Dag(gpu_ctx, dag)
+    d.set_probabilities(p)
+    got = d.run(SEED, 250_000)
+    assert got.hits == oracle.mc(dag, p, SEED, 250_000, n_threads=4)
+    mult = d.run(SEED, 1000, batch_size=5, sample_size=50)
+    assert mult.num_trials == 250_000 and mult.hits == got.hits
+    d.close()
