@@ -44,7 +44,10 @@ def main():
             rng = np.random.default_rng(1234)
             pt = np.minimum(1.0, p[None, :] * np.exp(sigma * rng.standard_normal((k, args.events))))
             logs = np.log(pt)
-            ctx.quantify_batch(model, logs[: min(k, 8)], prm, log_input=True)  # warm-up (allocations)
+            # warm-up with the SAME trials: the compact-CSR buffers grow (a synchronous hipFree + hipMalloc between the batch's
+            # events) the first time a batch lists more candidates than any before it -- round 2 warmed up with 8 trials and its
+            # first 64-trial batch at sigma 0.5 (2.0e6 candidates after 1.1e6) carried that growth: candidate_ms 1.55 instead of 0.6
+            ctx.quantify_batch(model, logs, prm, log_input=True)
             t0 = time.perf_counter()
             res, info = ctx.quantify_batch(model, logs, prm, log_input=True)
             wall_log_input = time.perf_counter() - t0
