@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcanopy.so")
+LIB_PATH = os.environ.get("CANOPY_AMD_LIB") or os.path.join(_HERE, "libcanopy.so")  # (the override: A/B of two builds on one box)
 
 PARTIAL_DOUBLES = 8
 
