@@ -10,8 +10,12 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_stats" -o fr -- \
   python3 "$R/bench.py" --no-cpu-baseline > "$O/${TAG}_stats.log" 2>&1 || echo "stats rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_stats_serial" -o fr -- \
+  python3 "$R/bench.py" --no-cpu-baseline --no-pipeline --no-also > "$O/${TAG}_stats_serial.log" 2>&1 || echo "serial stats rc=$?"
 cd "$R"
 timeout -k 10 500 python bench.py > "$O/${TAG}_bench.json" 2> "$O/${TAG}_bench.err" || echo "bench rc=$?"
+# the N > 1 launch path from a bare shell: two ranks on this one GPU (RCCL refuses duplicate devices: the torch / gloo fallback runs)
+timeout -k 10 300 python bench.py --gpus 2 --rehearse-backend gloo --steps 50 --warmup 5 > "$O/${TAG}_n2_rehearsal.json" 2> "$O/${TAG}_n2_rehearsal.err" || echo "n2 rc=$?"
 for n in 2 4 8; do
   timeout -k 10 200 python bench.py --shard-of $n --no-also --no-cpu-baseline > "$O/${TAG}_shard$n.json" 2> "$O/${TAG}_shard$n.err" || echo "shard$n rc=$?"
   timeout -k 10 200 python bench.py --shard-of $n --no-also --no-cpu-baseline --no-pipeline > "$O/${TAG}_shard${n}_serial.json" 2> "$O/${TAG}_shard${n}_serial.err" || echo "shard$n serial rc=$?"
