@@ -130,3 +130,16 @@ def test_combine_partials_matches_oracle(canopy_lib, oracle):
     none = _capi.Partial(0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -np.inf, -1.0)
     r = combine_partials([none, none])
     assert r.n_kept == 0 and r.argmax_row == -1 and r.rare_event == 0.0 and r.mcub == 0.0
+
+
+def test_default_library_carries_no_tuning_switches(canopy_lib):
+    """Round 3: the tuning switches and the wrong-result timing ablations of benchmarks/ (CANOPY_*_DEBUG, CANOPY_FR_*, ...) are
+    compiled in only with -DCANOPY_ABLATIONS; the library the product ships reads no environment variable (a stray variable
+    must never change a quantification). The names must not even occur in the binary, nor `getenv` among its imports."""
+    from canopy_amd import _capi
+    blob = open(_capi.LIB_PATH, "rb").read()
+    for name in (b"CANOPY_FR_DEBUG", b"CANOPY_WS_DEBUG", b"CANOPY_VS_DEBUG", b"CANOPY_MC_DEBUG", b"CANOPY_NO_PIPELINE",
+                 b"CANOPY_FR_", b"CANOPY_FX_", b"CANOPY_MC_", b"CANOPY_COMM_OWN_STREAM"):
+        assert name not in blob, name
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _capi.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert " getenv" not in undefined and "secure_getenv" not in undefined

@@ -116,3 +116,23 @@ def test_sharded_batch_gloo(tmp_path, oracle, canopy_lib):
         assert n_kept == whole.n_kept and argmax == whole.argmax_row and max_logp == whole.max_logp
         assert abs(rare - whole.rare_event) <= 1e-12 * whole.rare_event
         assert abs(mcub - whole.mcub) <= 1e-12 * whole.mcub
+
+
+def test_bench_launcher_starts_its_ranks_and_reports_a_dead_rank():
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE): the parent spawns its ranks before touching torch or the GPU
+    and relays their failure as a non-zero exit code instead of hanging. On this CPU-only container every rank stops with
+    "needs an MI355X" -- which is exactly the path "a rank died" of the launcher; on the GPU box the same command runs the
+    benchmark (profiles/r03_bench_n2_launcher_rehearsal.json)."""
+    import subprocess
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this is the CPU-side check of the launcher; the GPU run is benchmarks/evidence.sh")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--watchdog-s", "120"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""  # no JSON line from a run that did not measure anything
+    assert "needs an MI355X" in r.stderr and "stopping the others" in r.stderr or "needs an MI355X" in r.stderr
+    assert time.time() - t0 < 200
