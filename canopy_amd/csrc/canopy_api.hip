@@ -212,6 +212,7 @@ canopy_status canopy_ctx_synchronize(canopy_ctx* ctx) try {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, canopy::ctx_join_side(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& S : ctx->sets) S.pending_lo = 0; // everything enqueued so far has finished (what a writer of a probability set asks)
     return CANOPY_OK;
 } CANOPY_CATCH_ALL
 

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc_reg(McArgs a, McPlan plan) {
             if (tid < W) s_ticket[tid] = RSTEP;
             __syncthreads();
             int row = tid / W, t = 0, j = 0;
+            int next_row = 0; // the ticket of the item AFTER this one, drawn when this one starts: its LDS round trip hides under the item's hash rounds
             int k = 0;
             uint64_t ctr = 0, Tsh = 0, lt = 0, und = 0;
             bool active = row < n_rows;
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc_reg(McArgs a, McPlan plan) {
             while (__any(active)) {
                 if (active) {
                     if (fresh) {
+                        next_row = (int)atomicAdd(&s_ticket[wi], 1u);
                         t = (int)(((float)row + 0.5f) * inv_events); // row = t * n_events + j (row < 2^23: the float quotient is off by one at most)
                         if (t * a.n_events > row) --t;
                         else if ((t + 1) * a.n_events <= row) ++t;
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc_reg(McArgs a, McPlan plan) {
                     }
                     if (und == 0ULL || k == 53) { // k == 53 with lanes left: u == threshold, not below
                         stage[(size_t)row * W + wi] = lt; // stage[t][j][wi]
-                        row = (int)atomicAdd(&s_ticket[wi], 1u);
+                        row = next_row;
                         active = row < n_rows;
                         fresh = active;
                     }
