@@ -546,7 +546,9 @@ def main():
         import numpy as np
         rng = np.random.default_rng(7)
         variants_p = [np.clip(base_p * np.exp(0.05 * rng.standard_normal(base_p.shape)), 0.0, 1.0) for _ in range(8)]
-        el_p, last_p = timed_leg(args.also_steps, prm, set_p=lambda i: variants_p[i % 8])
+        n_newp = max(args.also_steps, 150)  # (a short leg measures the ramp after the previous leg, not the steady state)
+        run_steps(20, set_p=lambda i: variants_p[i % 8])
+        el_p, last_p = timed_leg(n_newp, prm, set_p=lambda i: variants_p[i % 8])
         logs = [np.log(v) for v in variants_p]
 
         def set_log(i):
@@ -564,10 +566,10 @@ def main():
                 last_ = fetch_ticket(inflight.pop(0))
             return last_
 
-        run_log_steps(3)
+        run_log_steps(20)
         ctx.synchronize()
         t0 = time.perf_counter()
-        run_log_steps(args.also_steps)
+        run_log_steps(n_newp)
         ctx.synchronize()
         el_l = time.perf_counter() - t0
         t0 = time.perf_counter()
@@ -577,10 +579,10 @@ def main():
         ctx.synchronize()
         model.set_probabilities(base_p)
         also["new_p"] = {
-            "ms_per_step": el_p * 1e3 / args.also_steps, "steps": args.also_steps,
-            "ms_per_step_log_input": el_l * 1e3 / args.also_steps,
+            "ms_per_step": el_p * 1e3 / n_newp, "steps": n_newp,
+            "ms_per_step_log_input": el_l * 1e3 / n_newp,
             "set_probabilities_host_ms": host_set_ms,
-            "cut_sets_per_s": info.n_rows * args.also_steps / el_p,
+            "cut_sets_per_s": info.n_rows * n_newp / el_p,
             "what": "every step: canopy_model_set_probabilities with a DIFFERENT vector (host log of %d values on the library's worker "
                     "threads + upload) -> canopy_quantify_enqueue -> canopy_ticket_fetch of the step two back; wall clock, host time "
                     "included; _log_input: canopy_model_set_log_probabilities instead" % info.n_events,
