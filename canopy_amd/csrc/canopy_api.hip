@@ -407,10 +407,19 @@ canopy_status set_values(canopy_ctx* ctx, canopy_model* m, const double* v, bool
     // the set (device buffer and staging buffer) must have no reader and no copy in flight left
     HIP_TRY(ctx, wait_set_readers(ctx, P));
     if (P.ev_write) HIP_TRY(ctx, hipEventSynchronize(P.ev_write));
-    if (!P.d_logp) {
-        HIP_TRY(ctx, hipMalloc(&P.d_logp, sizeof(double) * ev));
-        HIP_TRY(ctx, hipHostMalloc(&P.h_stage, sizeof(double) * ev));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&P.ev_write, hipEventDisableTiming));
+    if (!P.d_logp) { // first use of this set: all three resources or none (a half-made set must not look usable to the next call)
+        double* d = nullptr;
+        double* h = nullptr;
+        hipEvent_t evw = nullptr;
+        hipError_t e = hipMalloc(&d, sizeof(double) * ev);
+        if (e == hipSuccess) e = hipHostMalloc(&h, sizeof(double) * ev);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&evw, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (d) (void)hipFree(d);
+            if (h) (void)hipHostFree(h);
+            HIP_TRY(ctx, e);
+        }
+        P.d_logp = d; P.h_stage = h; P.ev_write = evw;
         m->device_bytes += (int64_t)(sizeof(double) * ev);
     }
     const int64_t bad = host_log_values(v, P.h_stage, m->n_events, is_log);
