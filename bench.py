@@ -626,6 +626,32 @@ def main():
             "n_kept": r0.n_kept, "rare_event": r0.rare_event, "mcub": r0.mcub, "layout_build_s": t_prep0,
         }
 
+        # (2b) K1 as literally stated: every cut set's s_i written out (40 B per cut set: CSR in, 8 B out), the exact CSR-order kernel
+        prm_r = canopy_amd.default_params(cut_off=args.cut_off, limit_order=20, flags=_capi.QUANT_ROW_LOGP, kernel=0)
+        t0 = time.time()
+        ctx.quantify_async(model, prm_r)  # builds the wave-slab stream on first use
+        ctx.synchronize()
+        t_prep_r = time.time() - t0
+        for _ in range(3):
+            ctx.quantify_async(model, prm_r)
+        ctx.synchronize()
+        ctx.timing_begin(10)
+        for _ in range(10):
+            ctx.quantify_async(model, prm_r)
+        ctx.synchronize()
+        _, _, n_r = ctx.timing_end()
+        l_r = ctx.timing_launches(n_r)
+        _, kr_med, kr_min = stats([a for a, _ in l_r])
+        v_r = ctx.last_kernel_variant()
+        bytes_r = info.algorithmic_bytes + 8 * info.n_rows
+        also["row_logp"] = {
+            "kernel_ran": v_r, "kernel": KERNEL_LABELS.get(v_r, "?"), "kernel_ms": {"median": kr_med, "min": kr_min},
+            "canonical_bytes_per_launch": bytes_r, "canonical_frac": bytes_r / (kr_med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "cut_sets_per_s": info.n_rows / (kr_med * 1e-3), "layout_build_s": t_prep_r,
+            "what": "CANOPY_QUANT_ROW_LOGP: the per-cut-set log-probabilities themselves (bit-exact CSR-order fp64 sums) written to HBM; "
+                    "bound by the texture addresser at wave-slab gather density (DESIGN.md, profiles/r03_microbench_gather_floor.txt)",
+        }
+
         # (3) the survivor cliff: the same pass at cut-offs more and more rows survive
         sel = []
         for co in (1e-9, 1e-10, 1e-11, 1e-12):
