@@ -2,12 +2,16 @@
 //
 // The canonical logp of the path is glibc's log evaluated on the host (include/canopy.h; the oracle restates the same
 // call), so a new BasicEvent::p() vector (reference src/mef/openpsa/event/event.h:93-96) costs E calls of log before
-// anything can be uploaded: ~1.5 ms on one core at E = 1e5, four times the 0.34 ms pass it feeds. The workers below take
-// that to ~0.1 ms; they are started by the first call that has enough values to share, sleep on a condition variable
-// between jobs and are never joined (a leaked singleton: nothing runs at process exit).
+// anything can be uploaded: ~1.5 ms on one core at E = 1e5, four times the 0.33 ms pass it feeds. The workers below take
+// that to well under 0.1 ms; they are started by the first call that has enough values to share and are never joined (a
+// leaked singleton: nothing runs at process exit). A sequence of quantifications calls in here every few hundred
+// microseconds: a worker that has just finished a job keeps polling for the next one for a short while before it goes to
+// sleep on the condition variable (a sleeping thread takes 50-100 us to come back, as much as the whole job), and the caller
+// polls for completion instead of sleeping.
 #include <math.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -19,17 +23,28 @@ namespace canopy {
 
 namespace {
 
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
+constexpr auto kSpinBeforeSleep = std::chrono::microseconds(400); // longer than the gap between two passes of a large model
+
 struct Pool {
     std::mutex mu;
-    std::condition_variable cv_work, cv_done;
+    std::condition_variable cv_work;
     std::vector<std::thread> workers;
-    // the one job in flight (callers are serialised by `gate`)
-    std::mutex gate;
+    std::mutex gate; // one job at a time
+    // the job in flight
     const std::function<void(int64_t, int64_t)>* fn = nullptr;
     int64_t n = 0, grain = 1;
     std::atomic<int64_t> next{0};
-    uint64_t generation = 0;
-    int running = 0;
+    std::atomic<uint64_t> generation{0};
+    std::atomic<int> running{0};
+    std::atomic<int> sleeping{0};
 
     void drain() { // take grains until none is left (workers and the caller alike)
         for (;;) {
@@ -42,14 +57,23 @@ struct Pool {
 
     void worker() {
         uint64_t seen = 0;
-        std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv_work.wait(lk, [&] { return generation != seen; });
-            seen = generation;
-            lk.unlock();
+            // poll for a while, then sleep
+            const auto t0 = std::chrono::steady_clock::now();
+            bool got = false;
+            while (std::chrono::steady_clock::now() - t0 < kSpinBeforeSleep) {
+                if (generation.load(std::memory_order_acquire) != seen) { got = true; break; }
+                cpu_relax();
+            }
+            if (!got) {
+                std::unique_lock<std::mutex> lk(mu);
+                sleeping.fetch_add(1, std::memory_order_relaxed);
+                cv_work.wait(lk, [&] { return generation.load(std::memory_order_acquire) != seen; });
+                sleeping.fetch_sub(1, std::memory_order_relaxed);
+            }
+            seen = generation.load(std::memory_order_acquire);
             drain();
-            lk.lock();
-            if (--running == 0) cv_done.notify_one();
+            running.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
 
@@ -93,13 +117,12 @@ void host_parallel_for(int64_t n, int64_t grain, const std::function<void(int64_
         p->n = n;
         p->grain = grain;
         p->next.store(0, std::memory_order_relaxed);
-        p->running = (int)p->workers.size();
-        ++p->generation;
+        p->running.store((int)p->workers.size(), std::memory_order_relaxed);
+        p->generation.fetch_add(1, std::memory_order_release);
     }
-    p->cv_work.notify_all();
+    if (p->sleeping.load(std::memory_order_relaxed) > 0) p->cv_work.notify_all();
     p->drain(); // the caller works too
-    std::unique_lock<std::mutex> lk(p->mu);
-    p->cv_done.wait(lk, [&] { return p->running == 0; });
+    while (p->running.load(std::memory_order_acquire) != 0) cpu_relax(); // (the job is tens of microseconds long)
     p->fn = nullptr;
 }
 
