@@ -174,7 +174,14 @@ canopy_status canopy_ctx_create(const canopy_ctx_params* params, canopy_ctx** ou
 void canopy_ctx_free(canopy_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->comm) canopy_comm_free(ctx->comm); // (the header asks for the communicator to go first: a forgotten one goes with its context)
+    if (ctx->comm) { // (the header asks for the communicator to go first) a forgotten one is DETACHED: its handle stays valid for
+        canopy_comm* c = ctx->comm; // the caller's canopy_comm_free, which then finds no context to touch
+        (void)canopy::ctx_join_side(ctx);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        c->ctx = nullptr;
+        ctx->comm = nullptr;
+    }
     for (int k = 1; k < canopy_ctx::kLanes; ++k) if (ctx->sets[k].stream) (void)hipStreamSynchronize(ctx->sets[k].stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto ev : ctx->ev_last) if (ev) (void)hipEventDestroy(ev);

@@ -166,7 +166,8 @@ struct canopy_ctx {
 };
 
 struct canopy_comm {
-    canopy_ctx* ctx = nullptr;
+    canopy_ctx* ctx = nullptr; // null once the context has been freed (canopy_ctx_free detaches; the handle stays the caller's to free)
+    int device = 0;
     void* comm = nullptr;   // ncclComm_t
     int world = 1, rank = 0;
     double* d_buf = nullptr; // [lanes][world][8] gather slots = the all-reduce buffers, one per lane of the context

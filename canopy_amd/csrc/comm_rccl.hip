@@ -117,7 +117,7 @@ void comm_release(canopy_comm* c) { // device / host resources only (not the RCC
 canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, canopy_comm** out) {
     canopy_comm* c = new (std::nothrow) canopy_comm();
     if (!c) return CANOPY_ERR_OUT_OF_MEMORY;
-    c->ctx = ctx; c->comm = nc; c->world = world; c->rank = rank;
+    c->ctx = ctx; c->device = ctx->device; c->comm = nc; c->world = world; c->rank = rank;
     if (hipSetDevice(ctx->device) != hipSuccess) {
         (void)hipGetLastError();
         delete c;
@@ -296,6 +296,8 @@ void canopy_comm_free(canopy_comm* c) {
             for (auto& S : ctx->sets) { S.d_gather = nullptr; S.ticket = 0; }
         }
         c->ctx = nullptr;
+    } else {
+        (void)hipSetDevice(c->device); // (the context went first: its streams were drained when it detached this communicator)
     }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl()->handle) (void)rccl()->CommDestroy(static_cast<ncclComm_t>(c->comm));

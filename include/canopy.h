@@ -342,8 +342,9 @@ CANOPY_API canopy_status canopy_ctx_set_gather_buffer(canopy_ctx* ctx, void* dev
  * The fold over the world records is done on the host in rank order: bitwise identical on every rank.
  * Monte-Carlo (K6): with a communicator attached (process-per-GPU shape) canopy_mc_run_async also sums
  * {hits, trials} over the ranks (one u64 all-reduce); canopy_comm_mc_fetch returns the global estimate.
- * canopy_comm_free detaches (the context returns to single-shard behaviour); free it before its context
- * (canopy_ctx_free takes a forgotten communicator with it).
+ * canopy_comm_free detaches (the context returns to single-shard behaviour); free it before its context. (If the context
+ * goes first, canopy_ctx_free detaches the communicator: every call on it then fails with CANOPY_ERR_INVALID_ARGUMENT except
+ * canopy_comm_free, which releases it.)
  * Streams: the all-reduce is enqueued right behind the pass's final reduce, on the lane that ran it
  * (canopy_ctx_set_pipeline): the next pass's row kernel streams on another lane while the (latency-bound) collective
  * of this one is on the wire. Consecutive passes therefore issue the collectives of one communicator from different

@@ -254,11 +254,15 @@ def test_comm_modes_and_comm_tickets_world_1(gpu_ctx):
     finally:
         comm.close()
     model.close()
-    # context freed first: the communicator goes with it; a later canopy_comm_free of the stale handle is NOT made
+    # context freed first: the communicator is detached (every call on it fails cleanly), its handle is still the caller's to free
     ctx2 = canopy_amd.Context(device=0)
     comm2 = canopy_amd.Comm(ctx2, canopy_amd.Comm.unique_id(), 1, 0)
-    comm2._h = None  # ownership passes to the context
     ctx2.close()
+    res = _capi.QuantResult()
+    import ctypes as C
+    assert _capi.lib().canopy_comm_fetch(comm2.handle, 0, C.byref(res), None) == _capi.ERR_INVALID_ARGUMENT
+    assert _capi.lib().canopy_comm_set_mode(comm2.handle, _capi.COMM_CHAINED) == _capi.ERR_INVALID_ARGUMENT
+    comm2.close()  # releases the RCCL communicator and the buffers; no context is touched
 
 
 @pytest.mark.gpu
