@@ -69,8 +69,17 @@ bool fr_q8_allowed() {
     return !off;
 }
 bool fr_use_q8(int32_t n_events) { return fr_q8_allowed() && n_events <= kQ8MaxParts * kQ8MaxEvents && n_events <= (1 << 18); }
+// Round 3: between 112 K and 254 K (260 096) events the table is kept at FOUR bits per event (levels 0..14, 15 = "alone enough to kill a
+// row"): it fits LDS in one piece, so the model needs no column parts and no second sweep; the coarser steps list about twice as
+// many rows for the exact pass (2 % instead of 0.9 % at the default cut-off), which costs less than the sweep it saves.
+constexpr int kQ4MaxEvents = 260096; // = 2 x (160 KiB - the 8192 + 128 u32 row sums - 128 counts): the 4-bit table fills the LDS to the byte
+constexpr int kQ4Levels = 14;
+bool fr_q8_nibble(int32_t n_events) {
+    static const bool off = CANOPY_TUNE_ENV("CANOPY_FR_NONIBBLE") != nullptr; // tuning only
+    return !off && fr_use_q8(n_events) && n_events > kQ8MaxEvents && n_events <= kQ4MaxEvents;
+}
 int fr_parts_for(int32_t n_events) {
-    if (!fr_use_q8(n_events) || n_events <= kQ8MaxEvents) return 1;
+    if (!fr_use_q8(n_events) || n_events <= kQ8MaxEvents || fr_q8_nibble(n_events)) return 1;
     return (n_events + kQ8MaxEvents - 1) / kQ8MaxEvents;
 }
 __host__ __device__ inline unsigned fr_bucket_of(uint32_t c, uint64_t ne) { return (unsigned)(((uint64_t)c * (uint64_t)kFrBucketsC) / ne); }
@@ -477,6 +486,25 @@ __global__ __launch_bounds__(256) void k_fr_q8_table(const double* __restrict__ 
     q8[j] = (uint8_t)(lv >= 255.0 ? 255 : (int)lv);
 }
 
+// the 4-bit form: two events per byte (event 2 b in the low half), levels clamp at 15
+__global__ __launch_bounds__(256) void k_fr_q4_table(const double* __restrict__ logp, int32_t n_events, double inv_step,
+                                                     uint8_t* __restrict__ q4) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * b >= n_events) return;
+    unsigned v = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = 2 * b + h;
+        unsigned q = 15u; // (the odd slot past the last event is never read)
+        if (j < n_events) {
+            const double lv = -logp[j] * inv_step * (1.0 - 0x1.0p-30); // as in k_fr_q8_table: a lower bound
+            q = lv >= 15.0 ? 15u : (unsigned)(int)lv;
+        }
+        v |= q << (4 * h);
+    }
+    q4[b] = (uint8_t)v;
+}
+
 constexpr int kQ8SlabRows = 8192, kQ8RowBits = 14, kQ8Waves = 16, kQ8Threads = kQ8Waves * kWave;
 constexpr uint32_t kQ8RowMask = (1u << kQ8RowBits) - 1;
 constexpr int kQ8Sinks = 128; // (the 24-bit stream's padding entries use the even ones: 8192 + 2 k)
@@ -527,7 +555,7 @@ __device__ __forceinline__ void q8_decode(const Q8Chunk& q, uint32_t (&col)[4], 
     }
 }
 
-template <int U, bool P24>
+template <int U, bool P24, bool NIB = false> // NIB: the table holds four bits per event (112 K < E <= 260 096)
 __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ cbase,
                                                              const int32_t* __restrict__ exc,
                                                              const int64_t* __restrict__ fr_off, int64_t total_chunks,
@@ -544,7 +572,8 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint32_t* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* sums = reinterpret_cast<unsigned*>(smem);
     uint8_t* tab = reinterpret_cast<uint8_t*>(smem + kQ8SumsBytes);
-    unsigned* s_cnt = reinterpret_cast<unsigned*>(smem + kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16); // [128]
+    const int tab_bytes = NIB ? (n_events + 1) / 2 : n_events;
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(smem + kQ8SumsBytes + (((size_t)tab_bytes + 15) / 16) * 16); // [128]
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -565,7 +594,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint32_t* __r
     { // the table, 16 bytes per lane per step (its buffer is padded to a multiple of 16)
         const uint4* src = reinterpret_cast<const uint4*>(q8);
         uint4* dst = reinterpret_cast<uint4*>(tab);
-        for (int i = tid; i < (n_events + 15) / 16; i += kQ8Threads) dst[i] = src[i];
+        for (int i = tid; i < (tab_bytes + 15) / 16; i += kQ8Threads) dst[i] = src[i];
     }
     fr_barrier();
 
@@ -593,7 +622,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8(const uint32_t* __r
                 q8_decode<P24>(q[u], col, row);
                 unsigned v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = tab[col[k]];
+                for (int k = 0; k < 4; ++k) v[k] = NIB ? ((unsigned)tab[col[k] >> 1] >> ((col[k] & 1u) << 2)) & 15u : (unsigned)tab[col[k]];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     __hip_atomic_fetch_add(&sums[row[k]], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1667,7 +1696,8 @@ __global__ __launch_bounds__(kFx2Waves * kWave) void k_fx2(const uint4* __restri
 // allocated) when more than 1 % of the slabs are exception slabs: the model then keeps the 32-bit form.
 bool fr_p24_applies(int32_t n_events) {
     static const bool off = CANOPY_TUNE_ENV("CANOPY_FR_NOP24") != nullptr; // tuning only
-    return !off && fr_use_q8(n_events) && fr_parts_for(n_events) == 1 && fr_slab_rows_for(n_events) == kQ8SlabRows;
+    // (not for the 4-bit table's range: beyond 112 K events a chunk spans more columns than the 10-bit offset holds)
+    return !off && fr_use_q8(n_events) && !fr_q8_nibble(n_events) && fr_parts_for(n_events) == 1 && fr_slab_rows_for(n_events) == kQ8SlabRows;
 }
 
 hipError_t fr_build_pack24(const uint32_t* d_stream32, const int64_t* d_fr_off, int64_t n_slabs, int64_t total_chunks, int32_t n_events,
@@ -1851,6 +1881,10 @@ void fr_q8_overlapped_units(int* unit_rows, int* units_per_slab) { *unit_rows = 
 // the 8-bit table of (logp, cut-off) by itself: q8_buf holds n_events bytes rounded up to 16
 hipError_t launch_fr_q8_table(const double* logp, int32_t n_events, double log_cut, uint8_t* q8_buf, hipStream_t s) {
     const double mag = -log_cut > 1.0 ? -log_cut : 1.0;
+    if (fr_q8_nibble(n_events)) {
+        hipLaunchKernelGGL(k_fr_q4_table, dim3(grid_for((n_events + 1) / 2, 256)), dim3(256), 0, s, logp, n_events, (double)kQ4Levels / mag, q8_buf);
+        return hipGetLastError();
+    }
     const double inv_step = (double)kQ8Levels / mag;
     hipLaunchKernelGGL(k_fr_q8_table, dim3(grid_for(n_events, 256)), dim3(256), 0, s, logp, n_events, inv_step, q8_buf);
     return hipGetLastError();
@@ -1861,14 +1895,14 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
                                double log_cut, uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count,
                                int n_cu, bool table_valid, hipStream_t s) {
     const double mag = -log_cut > 1.0 ? -log_cut : 1.0;
-    const double inv_step = (double)kQ8Levels / mag;
+    const bool nib = fr_q8_nibble(n_events);
+    const double inv_step = (double)(nib ? kQ4Levels : kQ8Levels) / mag;
     // s >= log_cut  ==>  sum(q) <= -log_cut / step; (1 + 2^-28): a hair generous, never too strict
     const double t = -log_cut * inv_step * (1.0 + 0x1.0p-28);
     const int threshold = t < 0.0 ? -1 : (t > 2.0e9 ? 2000000000 : (int)t);
     hipError_t e = hipSuccess;
     if (!table_valid) {
-        hipLaunchKernelGGL(k_fr_q8_table, dim3(grid_for(n_events, 256)), dim3(256), 0, s, logp, n_events, inv_step, q8_buf);
-        e = hipGetLastError();
+        e = launch_fr_q8_table(logp, n_events, log_cut, q8_buf, s);
         if (e != hipSuccess) return e;
     }
     static const int u = CANOPY_TUNE_ENV("CANOPY_FR_QU") ? atoi(CANOPY_TUNE_ENV("CANOPY_FR_QU")) : 4; // tuning only (chunks in flight per wave)
@@ -1927,7 +1961,7 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
         Q8P_GO(4);
 #undef Q8P_GO
     }
-    const size_t lds = kQ8SumsBytes + (((size_t)n_events + 15) / 16) * 16 + (kQ8SlabRows / 64) * 4;
+    const size_t lds = kQ8SumsBytes + (((size_t)(nib ? (n_events + 1) / 2 : n_events) + 15) / 16) * 16 + (kQ8SlabRows / 64) * 4;
     int64_t grid = n_cu;
     if (grid > n_slabs) grid = n_slabs;
     if (grid < 1) grid = 1;
@@ -1940,6 +1974,14 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
                            n_slabs, threshold, cand_list, cand_cnt, cand_count, fr_dbg);                                \
         return hipGetLastError();                                                                                       \
     } while (0)
+    if (nib) { // 112 K < E <= 260 096: the 4-bit table, the 32-bit stream (a chunk spans more columns than the 24-bit form's offset holds)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fr_filter_q8<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_fr_filter_q8<4, false, true>), dim3((unsigned)grid), dim3(kQ8Threads), lds, s, stream, (const uint32_t*)nullptr,
+                           (const int32_t*)nullptr, fr_off, total_chunks, q8_buf, n_events, n_rows, n_slabs, threshold, cand_list, cand_cnt,
+                           cand_count, fr_dbg);
+        return hipGetLastError();
+    }
     if (overlapped) { // adding and finishing waves side by side (list units of 4096 rows)
         if (p24 == nullptr || p24->stream == nullptr) return hipErrorInvalidValue;
         const size_t lds_o = kQ8oSumsBytes + (((size_t)n_events + 15) / 16) * 16 + 2 * kQ8Waves * 4;

@@ -254,11 +254,13 @@ def test_config3_full_size_properties(gpu_ctx, oracle):
     assert part_whole.n_kept == whole.n_kept
 
 
-@pytest.mark.parametrize("n_events", [114_689, 200_000, 229_376, 229_377, 262_144])
+@pytest.mark.parametrize("n_events", [114_689, 200_000, 260_096, 260_097, 262_144])
 def test_filter_refine_wide_event_space(gpu_ctx, oracle, n_events):
-    """Beyond 112 K events the 8-bit filter table is cut into 2 or 3 column parts, one resident per sweep, the row sums
-    carried between sweeps (114 689 = first size with two parts, 229 376 = last with two, 2^18 = the largest event space
-    of the slab stream: 18 column bits). Every variant against the oracle, FILTER_REFINE and FIXED_SUM included."""
+    """Beyond 112 K events the 8-bit filter table no longer fits LDS. Up to 260 096 (round 3) the table is kept at four bits per
+    event and the pass stays a single sweep (114 689 = the first such size, odd; 260 096 = the last: the table fills the 160 KiB
+    to the byte); beyond that the columns are cut into parts, one part of the 8-bit table resident per sweep, the row sums carried
+    between sweeps (260 097 = the first size with parts, 2^18 = the largest event space of the slab stream: 18 column bits). Every variant against the oracle,
+    FILTER_REFINE and FIXED_SUM included."""
     row_ptr, col = oracle.synth_csr(SEED, 300000, n_events, 6, n_threads=4)
     p = oracle.synth_probabilities(SEED, n_events)
     p[::7] = np.minimum(1.0, p[::7] * 3e3)  # some likely events: candidates with entries in every part
