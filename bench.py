@@ -654,7 +654,7 @@ def main():
 
         # (3) the survivor cliff: the same pass at cut-offs more and more rows survive
         sel = []
-        for co in (1e-9, 1e-10, 1e-11, 1e-12):
+        for co in (1e-9, 1e-10, 1e-11, 1e-12, 1e-13):  # ~2, 3.6, 5.7, 7.9, 10.5 % survivors (past 10 % listed AUTO hands over to FIXED_SUM)
             prm_s = canopy_amd.default_params(cut_off=co, limit_order=20, kernel=0)
             ctx.quantify_async(model, prm_s)
             ctx.fetch_partial()  # AUTO's feedback for this cut-off (it may leave filter/refine for the fixed-point pass)
