@@ -233,15 +233,15 @@ canopy_status plan_pass(canopy_ctx* ctx, const canopy_model* m, const PSet* P, c
     // AUTO: with a positive cut-off and no per-row output, filter/refine replaces the row kernels once the
     // model is large enough to amortise its launches (fr_min_rows), unless its filter listed too many of
     // the rows last time (fr_leave_at).
-    // Where filter/refine stops paying depends on what takes over: against the fixed-point pass (0.69 ms per 1e8 rows
-    // whatever the survivors) the crossover is at ~10 % of the rows listed (measured at config 3, pipelined steps, cut-offs
-    // 1e-9 .. 1e-13: 0.43 ms at 2 % survivors, 0.55 at 5.7 %, 0.68 at 8 %, 0.69 at 10 %), against the exact CSR-order
-    // stream kernel (1.2-1.5 ms) at ~20 %.
+    // Where filter/refine stops paying depends on what takes over: against the fixed-point pass (0.67 ms per 1e8 rows
+    // whatever the survivors) the crossover is at ~15 % of the rows listed (round 3, config 3, pipelined steps, cut-offs
+    // 1e-13 .. 1e-16: 0.597 ms at 10.3 % listed, 0.621 at 12.3 %, 0.650 at 14.4 %, 0.713 at 16.3 %; round 2: 10 % -- the exact
+    // pass has since got cheaper per listed row), against the exact CSR-order stream kernel (1.1-1.5 ms) at ~20 %.
     const bool fx_can_take_over = m->n_events >= 1 && m->n_events <= fr_max_events() && m->n_rows >= fx_min_rows(variant) &&
                                   m->max_row_len <= fx_max_row_len() &&
                                   !(ctx->fx_known_id == m->id && ctx->fx_known_fraction > 0.2 &&
                                     ctx->fx_known_cut_off == params->cut_off && ctx->fx_known_version == P->version);
-    const double fr_leave_at = fx_can_take_over ? 0.10 : 0.2;
+    const double fr_leave_at = fx_can_take_over ? 0.15 : 0.2;
     if (params->kernel == CANOPY_KERNEL_AUTO && params->cut_off > 0.0 && !pl.want_rows &&
         m->n_events >= 1 && m->n_events <= fr_max_events() && m->n_rows >= fr_min_rows(variant) &&
         !(ctx->fr_known_id == m->id && ctx->fr_known_fraction > fr_leave_at && ctx->fr_known_cut_off == params->cut_off &&
