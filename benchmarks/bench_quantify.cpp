@@ -2,8 +2,8 @@
 // target is an empty CMakeLists.txt, reference benchmarks/CMakeLists.txt). One GPU, one process:
 //   hipcc -std=c++17 -O2 -Iinclude benchmarks/bench_quantify.cpp -Lcanopy_amd -lcanopy -Wl,-rpath,$PWD/canopy_amd -o benchmarks/bench_quantify
 //   ./benchmarks/bench_quantify [rows=100000000] [events=100000] [avg_nnz=6] [steps=200] [warmup=20] [cut_off=1e-8]
-// Prints one JSON line: quantified cut-sets/s, device time per pass (HIP events inside the library), algorithmic
-// GB/s against the 8 TB/s HBM peak. bench.py is the driver the harness runs (it adds the multi-GPU launch, the CPU
+// Prints one JSON line: quantified cut-sets/s with every step's result fetched (per-pass tickets), device time per pass
+// (HIP events inside the library, serial probe), bytes moved per second against the 8 TB/s HBM peak. bench.py is the driver the harness runs (it adds the multi-GPU launch, the CPU
 // baseline and the oracle check); this file is the same measurement without Python in the loop.
 #include <chrono>
 #include <cstdio>
@@ -34,30 +34,54 @@ int main(int argc, char** argv) {
         }
         // 40 untimed spin-up passes first, as in bench.py: the GPU idled during the model build and its first ~20 launches
         // run through a clock / power transient (profiles/r01_filter_launch_sequence.txt)
+        const int lanes = 4; // (what bench.py uses for the whole model on one GPU)
+        if (canopy_ctx_set_pipeline(ctx.get(), lanes) != CANOPY_OK) return 4;
         for (int i = 0; i < 40 + warmup; ++i) ctx.quantify_async(model, prm);
         ctx.synchronize();
-        if (canopy_timing_begin(ctx.get(), steps) != CANOPY_OK) return 4;
+        // the timed steps: every pass enqueued with a ticket, every record fetched while up to lanes - 1 later passes are in flight
+        std::vector<canopy_ticket> inflight;
+        canopy_partial part{};
         const auto t0 = std::chrono::steady_clock::now();
-        for (int i = 0; i < steps; ++i) ctx.quantify_async(model, prm);
+        for (int i = 0; i < steps; ++i) {
+            inflight.push_back(ctx.enqueue(model, prm));
+            if ((int)inflight.size() == lanes) { part = ctx.fetch(inflight.front()); inflight.erase(inflight.begin()); }
+        }
+        for (canopy_ticket t : inflight) part = ctx.fetch(t);
         ctx.synchronize();
         const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        // instrumented serial probe: HIP events around the kernels of one pass at a time (on the stream they run on)
+        if (canopy_ctx_set_pipeline(ctx.get(), 0) != CANOPY_OK) return 4;
+        const int probe = steps < 50 ? steps : 50;
+        if (canopy_timing_begin(ctx.get(), probe) != CANOPY_OK) return 4;
+        for (int i = 0; i < probe; ++i) ctx.quantify_async(model, prm);
         double k_ms = 0.0, t_ms = 0.0;
         int32_t n = 0;
         if (canopy_timing_end(ctx.get(), &k_ms, &t_ms, &n) != CANOPY_OK || n < 1) return 5;
-        const canopy_partial part = ctx.fetch();
+        (void)ctx.fetch(); // (the legacy fetch of the last pass: it also hands AUTO the conservative pass's candidate count)
+        int64_t listed = 0, looked = 0;
+        (void)canopy_last_filter_candidates(ctx.get(), &listed, &looked);
         canopy_quant_result r;
         canopy_combine_partials(&part, 1, 0, &r);
         canopy_model_info info;
         canopy_model_get_info(model.get(), &info);
+        const int variant = (int)canopy_last_kernel_variant(ctx.get());
         const double ms_per_step = wall_ms / steps, kernel_ms = k_ms / n;
-        const double gbs = (double)info.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9;
+        // bytes the pass must move in the layout it reads (bench.py's moved_bytes): the slab stream + two 128-byte lines and a
+        // list entry per row handed to the exact pass; the canonical CSR for the other variants
+        double moved = (double)info.algorithmic_bytes;
+        if (variant == CANOPY_KERNEL_FILTER_REFINE && info.stream_bytes) moved = (double)info.stream_bytes + (double)listed * 260.0;
+        else if (variant == CANOPY_KERNEL_FIXED_SUM && info.stream_bytes_wide) moved = (double)info.stream_bytes_wide + (double)listed * 260.0;
+        else if (info.stream_bytes) moved = (double)info.stream_bytes;
+        const double gbs = moved / (kernel_ms * 1e-3) / 1e9;
         std::printf("{\"metric\": \"quantified cut-sets/sec\", \"value\": %.6g, \"unit\": \"cut-sets/s\", \"n_gpus\": 1, "
-                    "\"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.6g, \"avg_kernel_ms\": %.6g, \"kernel_ran\": %d, "
-                    "\"roofline\": {\"bound\": \"hbm\", \"achieved\": %.6g, \"peak\": 8000.0, \"unit\": \"GB/s\", \"frac\": %.6g}, "
+                    "\"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.6g, \"results_fetched_per_step\": true, \"lanes\": %d, "
+                    "\"avg_kernel_ms\": %.6g, \"kernel_ran\": %d, "
+                    "\"roofline\": {\"bound\": \"hbm\", \"achieved\": %.6g, \"peak\": 8000.0, \"unit\": \"GB/s\", \"frac\": %.6g, "
+                    "\"moved_bytes_per_launch\": %.6g, \"canonical_equivalent_frac\": %.6g}, "
                     "\"rows\": %lld, \"n_events\": %d, \"nnz\": %lld, \"rare_event\": %.17g, \"mcub\": %.17g, \"n_kept\": %lld, "
                     "\"argmax_row\": %lld}\n",
-                    (double)rows / (ms_per_step * 1e-3), steps, warmup, ms_per_step, kernel_ms,
-                    (int)canopy_last_kernel_variant(ctx.get()), gbs, gbs / 8000.0, (long long)info.n_rows, info.n_events,
+                    (double)rows / (ms_per_step * 1e-3), steps, warmup, ms_per_step, lanes, kernel_ms, variant, gbs, gbs / 8000.0, moved,
+                    (double)info.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 / 8000.0, (long long)info.n_rows, info.n_events,
                     (long long)info.nnz, r.rare_event, r.mcub, (long long)r.n_kept, (long long)r.argmax_row);
     } catch (const canopy::error& e) {
         std::fprintf(stderr, "canopy: %s\n", e.what());
