@@ -19,6 +19,25 @@ print("oracle quantify s", time.time() - t0, int(w.n_kept), int(w.argmax_row), w
 ok = got.n_kept == int(w.n_kept) and got.argmax_row == int(w.argmax_row) and got.max_logp == w.max_logp \
      and abs(got.rare_event - w.rare_event) <= 1e-12 * w.rare_event and abs(got.mcub - w.mcub) <= 1e-12 * w.mcub
 print("MATCH" if ok else "MISMATCH", "(cut_off 1e-8, AUTO)", flush=True)
+# the same pass timed: ticketed steps, every record fetched, four lanes
+ctx.set_pipeline(4)
+prm = canopy_amd.default_params()
+for _ in range(8):
+    ctx.quantify_async(m, prm)
+ctx.synchronize()
+inflight, n_steps, same = [], 40, True
+t0 = time.time()
+for _ in range(n_steps):
+    inflight.append(ctx.enqueue(m, prm))
+    if len(inflight) == 4:
+        r = canopy_amd.combine_partials([ctx.ticket_fetch(inflight.pop(0))]); same &= r.n_kept == got.n_kept and r.rare_event == got.rare_event
+for t in inflight:
+    r = canopy_amd.combine_partials([ctx.ticket_fetch(t)]); same &= r.n_kept == got.n_kept and r.rare_event == got.rare_event
+ctx.synchronize()
+dt = (time.time() - t0) / n_steps
+print("gpu cut_off 1e-8: ms per step %.3f (every result fetched, 4 lanes), %.3g cut-sets/s, every step's record %s the first pass's"
+      % (dt * 1e3, N / dt, "==" if same else "!="), flush=True)
+ctx.set_pipeline(0)
 # the same model with cut_off = 0: every row through exp / log1p (AUTO -> the fixed-point pass + exact refine of the contenders)
 prm0 = canopy_amd.default_params(cut_off=0.0)
 got0 = ctx.quantify(m, prm0)
