@@ -156,8 +156,11 @@ canopy_status canopy_ctx_create(const canopy_ctx_params* params, canopy_ctx** ou
             if (k > 0 && (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess ||
                           hipMalloc(&S.d_partial, sizeof(double) * CANOPY_PARTIAL_DOUBLES) != hipSuccess)) st = CANOPY_ERR_HIP;
             if (st == CANOPY_OK && hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming) != hipSuccess) st = CANOPY_ERR_HIP;
-            if (st == CANOPY_OK && hipHostMalloc(&S.h_rec, sizeof(double) * 2 * CANOPY_PARTIAL_DOUBLES) != hipSuccess) st = CANOPY_ERR_OUT_OF_MEMORY;
         }
+        if (st != CANOPY_OK) break;
+        if (hipHostMalloc(&ctx->h_ring, sizeof(double) * 2 * CANOPY_PARTIAL_DOUBLES * canopy_ctx::kTicketRing) != hipSuccess) { st = CANOPY_ERR_OUT_OF_MEMORY; break; }
+        for (auto& T : ctx->ring)
+            if (hipEventCreateWithFlags(&T.ev, hipEventDisableTiming) != hipSuccess) { st = CANOPY_ERR_HIP; break; }
         if (st != CANOPY_OK) break;
         static const bool no_pipe = CANOPY_TUNE_ENV("CANOPY_NO_PIPELINE") != nullptr; // tuning only
         ctx->pipeline_on = !no_pipe;
@@ -192,8 +195,9 @@ void canopy_ctx_free(canopy_ctx* ctx) {
         if (S.d_fr_cnt) (void)hipFree(S.d_fr_cnt);
         if (S.d_fr_count) (void)hipFree(S.d_fr_count);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-        if (S.h_rec) (void)hipHostFree(S.h_rec);
     }
+    for (auto& T : ctx->ring) if (T.ev) (void)hipEventDestroy(T.ev);
+    if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     for (int k = 1; k < canopy_ctx::kLanes; ++k) {
         if (ctx->sets[k].d_partial) (void)hipFree(ctx->sets[k].d_partial);
         if (ctx->sets[k].stream) (void)hipStreamDestroy(ctx->sets[k].stream);
@@ -530,33 +534,31 @@ canopy_status canopy_quantify_enqueue(canopy_ctx* ctx, const canopy_model* m, co
 // lane's event and a memcpy -- the other lanes keep running, nothing is joined, no device copy is enqueued.
 canopy_status canopy_ticket_fetch(canopy_ctx* ctx, canopy_ticket ticket, canopy_partial* out) try {
     if (!ctx || !out || ticket == 0) return CANOPY_ERR_INVALID_ARGUMENT;
-    for (auto& S : ctx->sets) {
-        if (S.ticket != ticket) continue;
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipEventSynchronize(S.ev_done));
-        if (S.last_seq == ticket) S.pending_lo = 0;
-        memcpy(out, S.h_rec, sizeof(canopy_partial));
-        unsigned long long count = 0;
-        memcpy(&count, S.h_rec + CANOPY_PARTIAL_DOUBLES, sizeof(count));
-        apply_feedback(ctx, S, count); // AUTO: a conservative pass that lists most rows is not worth its exact pass
-        return CANOPY_OK;
-    }
-    return fail(ctx, CANOPY_ERR_STATE, "ticket expired or unknown: a lane keeps the record of its LAST ticketed pass only (at most three "
-                                       "pipelined passes, one un-pipelined pass, may be outstanding)");
+    canopy_ctx::TicketSlot& T = ctx->ring[ticket % canopy_ctx::kTicketRing];
+    if (T.ticket != ticket)
+        return fail(ctx, CANOPY_ERR_STATE, "ticket expired or unknown: a record stays fetchable until 64 later passes have been enqueued on its context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(T.ev));
+    canopy_ctx::PassScratch& S = ctx->sets[T.lane];
+    if (S.last_seq == ticket) S.pending_lo = 0;
+    const double* rec = ctx->h_ring + (size_t)(ticket % canopy_ctx::kTicketRing) * 2 * CANOPY_PARTIAL_DOUBLES;
+    memcpy(out, rec, sizeof(canopy_partial));
+    unsigned long long count = 0;
+    memcpy(&count, rec + CANOPY_PARTIAL_DOUBLES, sizeof(count));
+    if (S.last_seq == ticket) apply_feedback(ctx, S, count); // AUTO: a conservative pass that lists most rows is not worth its exact pass
+    return CANOPY_OK;
 } CANOPY_CATCH_ALL
 
 canopy_status canopy_ticket_done(canopy_ctx* ctx, canopy_ticket ticket, int32_t* done) try {
     if (!ctx || !done || ticket == 0) return CANOPY_ERR_INVALID_ARGUMENT;
-    for (auto& S : ctx->sets) {
-        if (S.ticket != ticket) continue;
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        const hipError_t e = hipEventQuery(S.ev_done);
-        if (e != hipSuccess && e != hipErrorNotReady) HIP_TRY(ctx, e);
-        (void)hipGetLastError();
-        *done = e == hipSuccess ? 1 : 0;
-        return CANOPY_OK;
-    }
-    return fail(ctx, CANOPY_ERR_STATE, "ticket expired or unknown");
+    canopy_ctx::TicketSlot& T = ctx->ring[ticket % canopy_ctx::kTicketRing];
+    if (T.ticket != ticket) return fail(ctx, CANOPY_ERR_STATE, "ticket expired or unknown");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const hipError_t e = hipEventQuery(T.ev);
+    if (e != hipSuccess && e != hipErrorNotReady) HIP_TRY(ctx, e);
+    (void)hipGetLastError();
+    *done = e == hipSuccess ? 1 : 0;
+    return CANOPY_OK;
 } CANOPY_CATCH_ALL
 
 canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* out) try {

@@ -92,9 +92,6 @@ struct canopy_ctx {
         hipEvent_t ev_done = nullptr;       // end of the lane's last pass that recorded one
         bool pending = false;               // work on this lane the context's stream has not been ordered behind yet
         bool used = false;
-        // tickets: the record of the lane's last ticketed pass lands in pinned host memory (k_finalize writes it)
-        double* h_rec = nullptr;            // pinned [16]: the shard record [0..8), the filter's candidate total as u64 at [8]
-        uint64_t ticket = 0;                // pass number whose record h_rec (and the communicator's h_lane) will hold; 0 none
         uint64_t last_seq = 0;              // pass number of the lane's last pass
         uint64_t pending_lo = 0;            // lowest pass number on this lane not known to have finished (0 = none)
         bool last_has_event = false;        // ev_done was recorded behind the lane's last pass
@@ -108,6 +105,16 @@ struct canopy_ctx {
         uint64_t fb_version = 0;
         int32_t fb_variant = 0;
     } sets[kLanes];
+    // Tickets: the record of a ticketed pass lands in pinned host memory (k_finalize writes it), in slot `pass number mod
+    // kTicketRing` of a ring, with an event of its own behind the pass: a ticket stays fetchable until kTicketRing later
+    // passes have been enqueued on the context, whatever lanes they ran on (un-pipelined passes share lane 0).
+    static constexpr int kTicketRing = 64;
+    struct TicketSlot {
+        uint64_t ticket = 0;      // pass number whose record the slot holds / will hold; 0 none
+        int lane = 0;             // the lane that ran it (AUTO's feedback lives there)
+        hipEvent_t ev = nullptr;  // behind the pass (its collective and publish included)
+    } ring[kTicketRing];
+    double* h_ring = nullptr;     // pinned [kTicketRing][16]: the shard record [0..8), the filter's candidate total as u64 at [8]
     bool pipeline_on = true;      // canopy_ctx_set_pipeline
     int n_lanes = 3;              // lanes consecutive pipelined passes rotate through (2 .. kLanes)
     int pipe_next = 0;            // lane of the next pipelined pass
@@ -172,7 +179,7 @@ struct canopy_comm {
     int world = 1, rank = 0;
     double* d_buf = nullptr; // [lanes][world][8] gather slots = the all-reduce buffers, one per lane of the context
     double* h_buf = nullptr; // pinned mirror
-    double* h_lane[canopy_ctx::kLanes] = {}; // pinned [world][8]: the combined records of a lane's last ticketed pass
+    double* h_ring = nullptr; // pinned [canopy_ctx::kTicketRing][world][8]: the combined records of the ticketed passes (slot = pass number mod ring)
     // Ordering of consecutive collectives (canopy_comm_set_mode). CHAINED (default): the collective rides the lane that
     // ran the final reduce, behind an event recorded after the PREVIOUS collective of this communicator -- the device
     // runs the collectives of one communicator strictly in issue order whatever stream they are on. UNORDERED: no such
@@ -338,7 +345,7 @@ uint64_t next_object_id();
 // comm_rccl.hip
 // the single collective of a pass, enqueued on the stream its final reduce ran on; publish: also copy the combined
 // records into the lane's pinned buffer (ticketed pass)
-canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane, bool timed, bool publish);
+canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane, bool timed, int publish_slot);
 hipStream_t comm_stream(canopy_ctx* ctx);
 // orders the context's stream behind everything enqueued on the other lanes (device-side waits, no host blocking)
 hipError_t ctx_join_side(canopy_ctx* ctx);

@@ -105,7 +105,7 @@ void comm_release(canopy_comm* c) { // device / host resources only (not the RCC
     if (c->h_buf) (void)hipHostFree(c->h_buf);
     if (c->d_mc) (void)hipFree(c->d_mc);
     if (c->h_mc) (void)hipHostFree(c->h_mc);
-    for (auto h : c->h_lane) if (h) (void)hipHostFree(h);
+    if (c->h_ring) (void)hipHostFree(c->h_ring);
     for (auto e : c->ev_chain) if (e) (void)hipEventDestroy(e);
     if (c->ev_fin) (void)hipEventDestroy(c->ev_fin);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
@@ -132,7 +132,7 @@ canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, ca
     // recorded after the communicator's previous collective (canopy_comm_set_mode has the alternatives).
     c->mode = CANOPY_COMM_CHAINED;
     for (int k = 0; k < canopy_ctx::kLanes && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->ev_lane[k], hipEventDisableTiming);
-    for (int k = 0; k < canopy_ctx::kLanes && e == hipSuccess; ++k) e = hipHostMalloc(&c->h_lane[k], bytes);
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_ring, bytes * canopy_ctx::kTicketRing);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->ev_chain[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_mc, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_mc, 2 * sizeof(unsigned long long));
@@ -146,6 +146,7 @@ canopy_status comm_alloc(canopy_ctx* ctx, ncclComm_t nc, int world, int rank, ca
     canopy_status st = canopy_ctx_set_gather_buffer(ctx, c->d_buf, world, rank);
     if (st != CANOPY_OK) { canopy_comm_free(c); return st; }
     for (int k = 0; k < canopy_ctx::kLanes; ++k) ctx->sets[k].d_gather = c->d_buf + (size_t)k * CANOPY_PARTIAL_DOUBLES * (size_t)world;
+    for (auto& T : ctx->ring) T.ticket = 0; // (tickets of earlier passes have no combined records)
     ctx->comm = c;
     *out = c;
     return CANOPY_OK;
@@ -161,7 +162,7 @@ namespace canopy {
 // side) for an event recorded behind the previous one, so the device runs them strictly in issue order -- the same
 // order on every rank -- without relying on what RCCL does between streams. The edge sits in the lane's latency-bound
 // tail, not in front of the next pass's row kernel.
-canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane, bool timed, bool publish) {
+canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream, double* buf, int lane, bool timed, int publish_slot) {
     canopy_comm* c = ctx->comm;
     if (!c || c->deferred) return CANOPY_OK;
     hipStream_t st = lane_stream;
@@ -183,7 +184,9 @@ canopy_status comm_all_reduce_partials(canopy_ctx* ctx, hipStream_t lane_stream,
         c->chain_stream = st;
         c->chain_valid = true;
     }
-    if (publish) HIPC_TRY(ctx, canopy::launch_publish(buf, c->world * CANOPY_PARTIAL_DOUBLES, c->h_lane[lane], st));
+    if (publish_slot >= 0) // ticketed pass: the combined records into its slot of the pinned ring
+        HIPC_TRY(ctx, canopy::launch_publish(buf, c->world * CANOPY_PARTIAL_DOUBLES,
+                                             c->h_ring + (size_t)publish_slot * c->world * CANOPY_PARTIAL_DOUBLES, st));
     if (timed || st != lane_stream) HIPC_TRY(ctx, hipEventRecord(c->ev_done, st));
     c->timed_valid = timed;
     c->issued = true;
@@ -293,7 +296,8 @@ void canopy_comm_free(canopy_comm* c) {
         if (ctx->comm == c) {
             ctx->comm = nullptr;
             (void)canopy_ctx_set_gather_buffer(ctx, nullptr, 0, 0);
-            for (auto& S : ctx->sets) { S.d_gather = nullptr; S.ticket = 0; }
+            for (auto& S : ctx->sets) S.d_gather = nullptr;
+            for (auto& T : ctx->ring) T.ticket = 0; // (their combined records lived in this communicator)
         }
         c->ctx = nullptr;
     } else {
@@ -391,21 +395,23 @@ canopy_status canopy_comm_ticket_fetch(canopy_comm* c, canopy_ticket ticket, uin
     if (!c || !c->ctx || ticket == 0 || (!result && !parts)) return CANOPY_ERR_INVALID_ARGUMENT;
     canopy_ctx* ctx = c->ctx;
     if (c->deferred) return comm_fail(ctx, CANOPY_ERR_UNSUPPORTED, "tickets belong to the process-per-GPU shape (canopy_comm_init_rank)");
-    for (int k = 0; k < canopy_ctx::kLanes; ++k) {
-        canopy_ctx::PassScratch& S = ctx->sets[k];
-        if (S.ticket != ticket) continue;
-        HIPC_TRY(ctx, hipSetDevice(ctx->device));
-        HIPC_TRY(ctx, hipEventSynchronize(S.ev_done));
-        if (S.last_seq == ticket) S.pending_lo = 0;
+    const size_t slot = (size_t)(ticket % canopy_ctx::kTicketRing);
+    canopy_ctx::TicketSlot& T = ctx->ring[slot];
+    if (T.ticket != ticket)
+        return comm_fail(ctx, CANOPY_ERR_STATE, "ticket expired or unknown: records stay fetchable until 64 later passes have been enqueued on the context");
+    HIPC_TRY(ctx, hipSetDevice(ctx->device));
+    HIPC_TRY(ctx, hipEventSynchronize(T.ev));
+    canopy_ctx::PassScratch& S = ctx->sets[T.lane];
+    if (S.last_seq == ticket) {
+        S.pending_lo = 0;
         unsigned long long count = 0;
-        memcpy(&count, S.h_rec + CANOPY_PARTIAL_DOUBLES, sizeof(count));
+        memcpy(&count, ctx->h_ring + slot * 2 * CANOPY_PARTIAL_DOUBLES + CANOPY_PARTIAL_DOUBLES, sizeof(count));
         canopy::apply_feedback(ctx, S, count);
-        const canopy_partial* recs = reinterpret_cast<const canopy_partial*>(c->h_lane[k]);
-        if (parts) memcpy(parts, recs, sizeof(canopy_partial) * (size_t)c->world);
-        if (result) return canopy_combine_partials(recs, c->world, flags, result);
-        return CANOPY_OK;
     }
-    return comm_fail(ctx, CANOPY_ERR_STATE, "ticket expired or unknown: a lane keeps the records of its LAST ticketed pass only");
+    const canopy_partial* recs = reinterpret_cast<const canopy_partial*>(c->h_ring + slot * c->world * CANOPY_PARTIAL_DOUBLES);
+    if (parts) memcpy(parts, recs, sizeof(canopy_partial) * (size_t)c->world);
+    if (result) return canopy_combine_partials(recs, c->world, flags, result);
+    return CANOPY_OK;
 } CANOPY_CATCH_ALL
 
 canopy_status canopy_comm_last_collective_ms(canopy_comm* c, double* ms) try {

@@ -542,13 +542,15 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
     }
     if (timed) HIP_TRY(ctx, hipEventRecord(ev[1], lane));
     const bool publish = pl.ticketed && !ctx->capturing;
-    HIP_TRY(ctx, launch_finalize(S.d_block_partials, n_records, S.d_partial, d_gather, ctx->gather_world,
-                                 ctx->gather_rank, pl.two_step ? S.d_fr_count : nullptr, publish ? S.h_rec : nullptr, lane));
+    const int slot_t = (int)((ctx->seq + 1) % canopy_ctx::kTicketRing); // this pass's slot of the ticket ring
+    HIP_TRY(ctx, launch_finalize(S.d_block_partials, n_records, S.d_partial, d_gather, ctx->gather_world, ctx->gather_rank,
+                                 pl.two_step ? S.d_fr_count : nullptr,
+                                 publish ? ctx->h_ring + (size_t)slot_t * 2 * CANOPY_PARTIAL_DOUBLES : nullptr, lane));
     ctx->last_variant = pl.variant;
     ctx->last_set = set;
     hipStream_t last = lane; // the stream the pass ends on
     if (ctx->comm) { // K5: the one collective of the path, issued here (not by the host language), behind the final reduce
-        canopy_status cst = comm_all_reduce_partials(ctx, lane, d_gather, set, timed, publish);
+        canopy_status cst = comm_all_reduce_partials(ctx, lane, d_gather, set, timed, publish ? slot_t : -1);
         if (cst != CANOPY_OK) return cst;
         if (comm_stream(ctx)) last = comm_stream(ctx);
     }
@@ -563,7 +565,10 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
         S.pending = set != 0 || last != lane;
         S.last_has_event = true;
     }
-    S.ticket = publish ? seq : 0;
+    canopy_ctx::TicketSlot& T = ctx->ring[slot_t]; // (the pass 64 back loses its ticket here, fetched or not)
+    T.ticket = publish ? seq : 0;
+    T.lane = set;
+    if (publish) HIP_TRY(ctx, hipEventRecord(T.ev, last));
     if (opt.ticket_out) *opt.ticket_out = publish ? seq : 0;
     if (!ctx->capturing) { // who reads the set, and up to which pass: what the next writer of the set waits for
         if (P->reader_ctx == 0 || P->reader_ctx == ctx->id) { P->reader_ctx = ctx->id; P->read_hi = seq; }

@@ -95,7 +95,7 @@ class Context:
 
     def enqueue(self, model, params=None):
         """quantify_async + a ticket: the pass's record can be fetched with ticket_fetch() while later passes run
-        (canopy_quantify_enqueue). At most three pipelined passes may be outstanding; fetch in enqueue order."""
+        (canopy_quantify_enqueue). A ticket stays fetchable until 64 later passes have been enqueued on the context."""
         t = C.c_uint64()
         capi.check(capi.lib().canopy_quantify_enqueue(self._h, model.handle, C.byref(params) if params else None, C.byref(t)),
                    "canopy_quantify_enqueue", self._h)

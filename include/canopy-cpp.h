@@ -80,7 +80,7 @@ public:
         return p;
     }
     // one result per pass while later passes run: enqueue() hands out a ticket, fetch(ticket) waits for that pass only
-    // (at most three pipelined passes outstanding, fetched in enqueue order)
+    // (a ticket stays fetchable until 64 later passes have been enqueued on the context)
     canopy_ticket enqueue(const model_ptr& m, const canopy_quant_params& params = quant_params()) const {
         canopy_ticket t = 0;
         check(canopy_quantify_enqueue(get(), m.get(), &params, &t), "canopy_quantify_enqueue");

@@ -293,12 +293,12 @@ CANOPY_API canopy_status canopy_quantify_fetch(canopy_ctx* ctx, canopy_partial* 
 /*
  * Tickets: one result per pass without serialising the passes. canopy_quantify_enqueue is canopy_quantify_async plus a
  * ticket (the pass's number on this context, never 0); the pass's final reduce also writes its record into pinned host
- * memory of the lane it ran on, so canopy_ticket_fetch is a wait for THAT lane's completion event and a memcpy -- no
- * other lane is joined, no device copy is enqueued. A lane keeps the record of its last ticketed pass only: with
- * pipelining on, a ticket stays valid until as many ticketed pipelined passes as there are lanes (three by default) have
- * been enqueued after it (fetch in enqueue order, at most that many outstanding); un-pipelined passes share one lane
- * (fetch before the next enqueue). An expired
- * ticket gives CANOPY_ERR_STATE. canopy_ticket_done polls without blocking. With a communicator attached
+ * memory -- slot (ticket mod 64) of a ring -- with an event of its own behind the pass, so canopy_ticket_fetch is a wait
+ * for THAT pass and a memcpy: no lane is joined, no device copy is enqueued. A ticket stays fetchable, in any order and
+ * any number of times, until 64 later passes (ticketed or not, pipelined or not) have been enqueued on the context;
+ * after that, and after a communicator has been attached to or freed from the context, it gives CANOPY_ERR_STATE.
+ * (How many passes are IN FLIGHT is bounded by the lanes, not by the ring: enqueue blocks the host while the lane it
+ * needs is still busy.) canopy_ticket_done polls without blocking. With a communicator attached
  * (canopy_comm_init_rank) canopy_comm_ticket_fetch delivers the COMBINED result of the pass.
  */
 typedef uint64_t canopy_ticket;
@@ -384,8 +384,8 @@ CANOPY_API canopy_status canopy_combine_partials(const canopy_partial* parts, in
    parts[world_size] may be NULL. flags: CANOPY_QUANT_CLAMP. */
 CANOPY_API canopy_status canopy_comm_fetch(canopy_comm* comm, uint32_t flags, canopy_quant_result* result,
                                            canopy_partial* parts);
-/* The same for the pass of a ticket (canopy_quantify_enqueue on the communicator's context): waits for that pass's lane
-   only. Every rank holds the same records, so every rank gets the same result. */
+/* The same for the pass of a ticket (canopy_quantify_enqueue on the communicator's context): waits for that pass
+   only; valid as long as the ticket is. Every rank holds the same records, so every rank gets the same result. */
 CANOPY_API canopy_status canopy_comm_ticket_fetch(canopy_comm* comm, canopy_ticket ticket, uint32_t flags,
                                                   canopy_quant_result* result, canopy_partial* parts);
 

@@ -12,7 +12,7 @@ TOL = 1e-12
 
 
 def random_model(rng):
-    n_events = int(rng.choice([1, 2, 3, 7, 64, 65, 1000, 2049, 5000, 20000, 120000, 230000]))  # (the last two: the filter's column parts)
+    n_events = int(rng.choice([1, 2, 3, 7, 64, 65, 1000, 2049, 5000, 20000, 120000, 200000, 230000, 262144]))  # (the last four: the 4-bit table / column parts)
     n_rows = int(rng.choice([1, 2, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 16385, 30011]))
     max_len = int(min(n_events, rng.choice([1, 2, 4, 10, 25])))
     lens = rng.integers(0 if rng.random() < 0.3 else 1, max_len + 1, size=n_rows)
@@ -100,6 +100,53 @@ def test_random_models_every_variant(gpu_ctx, oracle, seed):
                                       want_rows=False))
     model.close()
     assert n_rows >= 1
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CANOPY_FUZZ_SEEDS", "24")) // 2))
+def test_random_ticketed_sequences(gpu_ctx, oracle, seed):
+    """Random sequences of (new p or new log p or the old one, a new cut-off or the old one, a ticketed pass) over TWO random
+    models on 2..4 lanes, records fetched in enqueue order with a random number of passes outstanding: every record against
+    the oracle's for the vector and cut-off ITS pass was enqueued with."""
+    import canopy_amd
+    from canopy_amd import default_params
+    rng = np.random.default_rng(9000 + seed)
+    lanes = int(rng.integers(2, 5))
+    models = []
+    for _ in range(2):
+        n_events, row_ptr, col, p, cut_off, limit_order = random_model(rng)
+        m = gpu_ctx.upload(row_ptr, col, n_events)
+        m.set_probabilities(p)
+        models.append(dict(m=m, n_events=n_events, row_ptr=row_ptr, col=col, p=p.copy(), limit_order=limit_order, cut_off=cut_off))
+    gpu_ctx.set_pipeline(lanes)
+    try:
+        inflight = []  # (ticket, expected)
+
+        def fetch_one():
+            t, want = inflight.pop(0)
+            agree(canopy_amd.combine_partials([gpu_ctx.ticket_fetch(t)]), want)
+
+        for step in range(int(rng.integers(6, 16))):
+            d = models[int(rng.integers(0, 2))]
+            u = rng.random()
+            if u < 0.4:  # a new probability vector
+                d["p"] = np.clip(d["p"] * np.exp(0.4 * rng.standard_normal(d["n_events"])), 0.0, 1.0)
+                d["m"].set_probabilities(d["p"])
+            elif u < 0.6:  # caller-supplied logs: the library must take them as they are
+                d["p"] = np.clip(d["p"] * np.exp(0.4 * rng.standard_normal(d["n_events"])), 1e-300, 1.0)
+                d["m"].set_log_probabilities(np.array([math.log(x) for x in d["p"]]))  # (math.log = libm's log, the oracle's)
+            if rng.random() < 0.3:
+                d["cut_off"] = float(rng.choice([0.0, 1e-12, 1e-8, 1e-3]))
+            want = oracle.quantify(d["row_ptr"], d["col"], d["p"], cut_off=d["cut_off"], limit_order=d["limit_order"], n_threads=2,
+                                   want_rows=False)
+            inflight.append((gpu_ctx.enqueue(d["m"], default_params(cut_off=d["cut_off"], limit_order=d["limit_order"])), want))
+            while len(inflight) >= lanes or (inflight and rng.random() < 0.3):
+                fetch_one()
+        while inflight:
+            fetch_one()
+    finally:
+        gpu_ctx.set_pipeline(True)
+        for d in models:
+            d["m"].close()
 
 
 def random_dag(rng):

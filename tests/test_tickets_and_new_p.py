@@ -74,8 +74,8 @@ def test_tickets_new_p_every_pass_equals_serial_passes(gpu_ctx, oracle):
 
 @pytest.mark.gpu
 def test_ticket_rules(gpu_ctx):
-    """A lane keeps its last ticketed record only: the fourth pipelined pass expires the first ticket; un-ticketed
-    passes hand out no ticket; ticket_done polls; the legacy fetch still delivers the last pass."""
+    """A ticket stays fetchable (any order, repeatedly) until 64 later passes have been enqueued, then expires; ticket_done
+    polls; the legacy fetch still delivers the last pass; un-pipelined passes in a row keep their records too."""
     import canopy_amd
     from canopy_amd import _capi
     n, e = 1_200_000, 5000
@@ -83,23 +83,32 @@ def test_ticket_rules(gpu_ctx):
     model.set_probabilities(canopy_amd.synthetic_probabilities(SEED, e))
     prm = canopy_amd.default_params(cut_off=1e-9)
     gpu_ctx.set_pipeline(True)
-    t = [gpu_ctx.enqueue(model, prm) for _ in range(4)]
-    assert len(set(t)) == 4 and all(x > 0 for x in t)
-    with pytest.raises(_capi.CanopyError) as err:
-        gpu_ctx.ticket_fetch(t[0])  # its lane has since run pass 3
-    assert err.value.status == _capi.ERR_STATE
-    recs = [gpu_ctx.ticket_fetch(x) for x in t[1:]]
+    t = [gpu_ctx.enqueue(model, prm) for _ in range(9)]
+    assert len(set(t)) == 9 and all(x > 0 for x in t)
+    recs = [gpu_ctx.ticket_fetch(x) for x in reversed(t)]  # any order, lanes long since reused
     assert all(_same(recs[0], r) for r in recs[1:])
-    assert gpu_ctx.ticket_done(t[3])
+    assert _same(gpu_ctx.ticket_fetch(t[0]), recs[0])  # and again
+    assert gpu_ctx.ticket_done(t[8])
     last = gpu_ctx.fetch_partial()
     assert _same(last, recs[-1])
     with pytest.raises(_capi.CanopyError):
         gpu_ctx.ticket_fetch(987654321)
-    # un-pipelined variants carry tickets too (lane 0)
-    prm_rows = canopy_amd.default_params(cut_off=1e-9, kernel=_capi.KERNEL_ROWS)
-    tk = gpu_ctx.enqueue(model, prm_rows)
-    r = gpu_ctx.ticket_fetch(tk)
-    assert r.n_kept == recs[0].n_kept and r.argmax_row == recs[0].argmax_row and r.max_logp == recs[0].max_logp
+    # un-pipelined variants carry tickets too (they share lane 0): three in a row, each with a different cut-off
+    cuts = (1e-9, 1e-7, 0.0)
+    tk = [gpu_ctx.enqueue(model, canopy_amd.default_params(cut_off=c, kernel=_capi.KERNEL_ROWS)) for c in cuts]
+    rr = [gpu_ctx.ticket_fetch(x) for x in tk]
+    assert rr[0].n_kept == recs[0].n_kept and rr[0].argmax_row == recs[0].argmax_row and rr[0].max_logp == recs[0].max_logp
+    assert rr[0].n_kept > rr[1].n_kept > 0 and rr[2].n_kept == n
+    # 64 later passes (un-ticketed ones count) expire a ticket
+    for _ in range(64 - len(tk) - 1):
+        gpu_ctx.quantify_async(model, prm)
+    assert gpu_ctx.ticket_fetch(t[8]).n_kept == recs[0].n_kept  # t[8] + 1 (legacy fetch: no pass) ... still inside the ring
+    gpu_ctx.quantify_async(model, prm)
+    gpu_ctx.quantify_async(model, prm)
+    with pytest.raises(_capi.CanopyError) as err:
+        gpu_ctx.ticket_fetch(t[8])
+    assert err.value.status == _capi.ERR_STATE
+    gpu_ctx.synchronize()
     model.close()
 
 
@@ -337,12 +346,9 @@ def test_lane_count_is_a_runtime_knob(gpu_ctx, lanes):
         while tickets:
             got.append(gpu_ctx.ticket_fetch(tickets.pop(0)))
         assert len(got) == len(serial) and all(_same(a, b) for a, b in zip(got, serial))
-        # exactly `lanes` tickets stay valid
-        t = [gpu_ctx.enqueue(model, prm) for _ in range(lanes + 1)]
-        from canopy_amd import _capi
-        with pytest.raises(_capi.CanopyError):
-            gpu_ctx.ticket_fetch(t[0])
-        for x in t[1:]:
+        # tickets outlive the reuse of their lane
+        t = [gpu_ctx.enqueue(model, prm) for _ in range(2 * lanes + 1)]
+        for x in t:
             assert _same(gpu_ctx.ticket_fetch(x), serial[-1])
     finally:
         gpu_ctx.set_pipeline(1)  # the default rotation
