@@ -219,7 +219,8 @@ def traffic_for(variant, info, cut_off):
 KERNEL_LABELS = {1: "k_rows (lane per row, L2 gather)", 2: "k_rows (lane per row, LDS table)",
                  3: "k_ws (wave-slab stream, exact CSR-order sums)", 4: "k_vs (value scatter)",
                  5: "k_fr_filter_q8 + k_fr_refine (quantised conservative filter, then exact refine)",
-                 6: "k_fx2 + k_fr_refine (order-independent fixed-point sums, exact refine of the undecided rows)"}
+                 6: "k_fx2 + k_fr_refine (order-independent fixed-point sums, exact refine of the undecided rows)",
+                 7: "k_bs (band stream: workgroup-wide slabs, a barrier between column-sorted bands, exact CSR-order sums)"}
 
 
 def stats(xs):
@@ -244,6 +245,8 @@ def moved_bytes(variant, info, listed_rows):
         return info.stream_bytes + (listed_rows or 0) * (2 * 128 + 4)
     if variant == 6 and info.stream_bytes_wide:  # the fixed-point pass streams the 32-bit form of the slab stream
         return info.stream_bytes_wide + (listed_rows or 0) * (2 * 128 + 4)
+    if variant in (3, 7) and info.stream_bytes_exact:
+        return info.stream_bytes_exact
     if variant in (3, 4) and info.stream_bytes:
         return info.stream_bytes
     return info.algorithmic_bytes
@@ -629,7 +632,7 @@ def main():
         # (2b) K1 as literally stated: every cut set's s_i written out (40 B per cut set: CSR in, 8 B out), the exact CSR-order kernel
         prm_r = canopy_amd.default_params(cut_off=args.cut_off, limit_order=20, flags=_capi.QUANT_ROW_LOGP, kernel=0)
         t0 = time.time()
-        ctx.quantify_async(model, prm_r)  # builds the wave-slab stream on first use
+        ctx.quantify_async(model, prm_r)  # builds the band stream on first use
         ctx.synchronize()
         t_prep_r = time.time() - t0
         for _ in range(3):
@@ -644,12 +647,16 @@ def main():
         _, kr_med, kr_min = stats([a for a, _ in l_r])
         v_r = ctx.last_kernel_variant()
         bytes_r = info.algorithmic_bytes + 8 * info.n_rows
+        info_r = model.info()
+        moved_r = moved_bytes(v_r, info_r, 0) + 8 * info.n_rows  # the stream the kernel reads + the s_i it writes
         also["row_logp"] = {
             "kernel_ran": v_r, "kernel": KERNEL_LABELS.get(v_r, "?"), "kernel_ms": {"median": kr_med, "min": kr_min},
+            "frac": moved_r / (kr_med * 1e-3) / 1e9 / HBM_PEAK_GBS, "moved_bytes_per_launch": moved_r,
             "canonical_bytes_per_launch": bytes_r, "canonical_frac": bytes_r / (kr_med * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "cut_sets_per_s": info.n_rows / (kr_med * 1e-3), "layout_build_s": t_prep_r,
-            "what": "CANOPY_QUANT_ROW_LOGP: the per-cut-set log-probabilities themselves (bit-exact CSR-order fp64 sums) written to HBM; "
-                    "bound by the texture addresser at wave-slab gather density (DESIGN.md, profiles/r03_microbench_gather_floor.txt)",
+            "what": "CANOPY_QUANT_ROW_LOGP: the per-cut-set log-probabilities themselves (bit-exact CSR-order fp64 sums) written to HBM "
+                    "(SURVEY 8(d): 40 B per cut set canonical); bound by the LDS fp64 adds and the table gathers of the band stream "
+                    "(DESIGN.md 3, benchmarks/microbench8.hip)",
         }
 
         # (3) the survivor cliff: the same pass at cut-offs more and more rows survive

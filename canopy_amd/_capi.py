@@ -32,7 +32,7 @@ QUANT_CLAMP, QUANT_ROW_LOGP, QUANT_KEEP_MASK, QUANT_IMPORTANCE = 1, 2, 4, 8
 BATCH_LOG_INPUT = 1
 GATE_AND, GATE_OR, GATE_ATLEAST, GATE_XOR, GATE_NOT, GATE_NAND, GATE_NOR, GATE_NULL = range(8)
 COMM_CHAINED, COMM_UNORDERED, COMM_OWN_STREAM = 0, 1, 2
-KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER, KERNEL_FILTER_REFINE, KERNEL_FIXED_SUM = range(7)
+KERNEL_AUTO, KERNEL_ROWS, KERNEL_ROWS_LDS, KERNEL_WAVE_STREAM, KERNEL_VALUE_SCATTER, KERNEL_FILTER_REFINE, KERNEL_FIXED_SUM, KERNEL_BAND_STREAM = range(8)
 
 
 class CtxParams(C.Structure):
@@ -48,7 +48,7 @@ class ModelInfo(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("nnz", C.c_int64), ("row_offset", C.c_int64),
                 ("n_events", C.c_int32), ("max_row_len", C.c_int32),
                 ("device_bytes", C.c_int64), ("stream_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64),
-                ("stream_bytes_wide", C.c_int64)]
+                ("stream_bytes_wide", C.c_int64), ("stream_bytes_exact", C.c_int64)]
 
 
 class QuantParams(C.Structure):

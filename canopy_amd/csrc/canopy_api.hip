@@ -46,6 +46,10 @@ void free_model_buffers(canopy_model* m) {
         P = PSet();
     }
     m->cur = -1;
+    if (m->d_bs_stream) (void)hipFree(m->d_bs_stream);
+    if (m->d_bs_off) (void)hipFree(m->d_bs_off);
+    if (m->d_bs_used) (void)hipFree(m->d_bs_used);
+    m->d_bs_stream = nullptr; m->d_bs_off = nullptr; m->d_bs_used = nullptr; m->bs_state = 0;
     if (m->d_ws_stream) (void)hipFree(m->d_ws_stream);
     if (m->d_ws_off) (void)hipFree(m->d_ws_off);
     if (m->d_vs_stream) (void)hipFree(m->d_vs_stream);
@@ -384,6 +388,11 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
         info->stream_bytes = m->vs_total_chunks * 1024 + (m->n_slabs + 1) * 16 + (m->n_rows + 1) * 8 + (int64_t)m->n_events * 8;
     else if (m->ws_state == 1)
         info->stream_bytes = m->ws_total_chunks * 1024 + (m->n_ws + 1) * 8 + (int64_t)m->n_events * 8;
+    info->stream_bytes_exact = 0;
+    if (m->bs_state == 1)
+        info->stream_bytes_exact = m->bs_used_ss * 16384 + m->n_bs_slabs * 12 + (int64_t)m->n_events * 8;
+    else if (m->ws_state == 1)
+        info->stream_bytes_exact = m->ws_total_chunks * 1024 + (m->n_ws + 1) * 8 + (int64_t)m->n_events * 8;
     info->algorithmic_bytes = (m->n_rows + 1) * 8 + m->nnz * 4 + (int64_t)m->n_events * 8;
     return CANOPY_OK;
 } CANOPY_CATCH_ALL
@@ -503,7 +512,14 @@ canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, int32_t ker
             return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a value-scatter stream");
         return CANOPY_OK; // AUTO: quantify falls back to ROWS
     }
-    if (variant != CANOPY_KERNEL_WAVE_STREAM) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
+    if (variant == CANOPY_KERNEL_BAND_STREAM) {
+        canopy_status st = build_bs(ctx, m, kernel == CANOPY_KERNEL_BAND_STREAM);
+        if (st != CANOPY_OK) return st;
+        if (m->bs_state == 1) return CANOPY_OK;
+        if (kernel == CANOPY_KERNEL_BAND_STREAM) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a band stream");
+        if (m->n_events > ws_max_events()) return CANOPY_OK; // AUTO: quantify falls back to ROWS
+        // AUTO: the wave-slab stream instead
+    } else if (variant != CANOPY_KERNEL_WAVE_STREAM) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
     canopy_status st = build_ws(ctx, m);
     if (st != CANOPY_OK) return st;
     if (m->ws_state != 1 && kernel == CANOPY_KERNEL_WAVE_STREAM)

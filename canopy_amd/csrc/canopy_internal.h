@@ -261,6 +261,12 @@ struct canopy_model {
     mutable int64_t* d_ws_off = nullptr;
     mutable int64_t ws_total_chunks = 0, n_ws = 0;
     mutable int ws_state = 0; // 0 not built, 1 ready, -1 not representable (fall back to ROWS)
+    // derived band stream (kernels_bs.hip): the exact all-rows kernel with workgroup-wide slabs
+    mutable uint32_t* d_bs_stream = nullptr;
+    mutable int64_t* d_bs_off = nullptr;   // [n_bs_slabs + 1] first superstep of every slab (allotted, not all used)
+    mutable int32_t* d_bs_used = nullptr;  // [n_bs_slabs] supersteps the slab uses
+    mutable int64_t bs_total_ss = 0, bs_used_ss = 0, n_bs_slabs = 0;
+    mutable int bs_state = 0; // 0 not built, 1 ready, -1 not representable, -2 representable only with > 30 % padding (explicit requests)
     // derived value-scatter layout (kernels_vs.hip)
     mutable uint32_t* d_vs_stream = nullptr;
     mutable int64_t* d_vs_off = nullptr;
@@ -337,6 +343,7 @@ canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m);
 canopy_status ensure_fr32(canopy_ctx* ctx, const canopy_model* m);
 canopy_status build_vs(canopy_ctx* ctx, const canopy_model* m);
 canopy_status build_ws(canopy_ctx* ctx, const canopy_model* m);
+canopy_status build_bs(canopy_ctx* ctx, const canopy_model* m, bool explicit_request);
 int auto_variant(const canopy_model* m);
 int64_t fr_min_rows(int base_variant);
 canopy_status fail(canopy_ctx* ctx, canopy_status st, const std::string& msg);
@@ -362,6 +369,15 @@ hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, con
                             int64_t total_chunks, int64_t n_ws, int need_len, int grid, int* n_records,
                             hipStream_t s);
 
+// kernels_bs.hip
+int bs_max_events();
+int bs_slab_rows();
+int bs_default_grid(int n_cu, int64_t n_slabs);
+hipError_t bs_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int64_t nnz, int32_t n_events,
+                    int32_t max_row_len, bool accept_padding, uint32_t** d_stream_out, int64_t** d_off_out, int32_t** d_used_out,
+                    int64_t* total_ss_out, int64_t* used_ss_out, int64_t* n_slabs_out, bool* ok, hipStream_t s);
+hipError_t launch_bs_kernel(const RowKernelArgs& ra, const uint32_t* stream, const int64_t* ss_off, const int32_t* ss_used, int64_t total_ss,
+                            int64_t n_slabs, int need_len, int grid, int* n_records, hipStream_t s);
 
 // kernels_vs.hip
 int vs_max_events();

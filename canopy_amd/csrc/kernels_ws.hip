@@ -111,73 +111,7 @@ __device__ __forceinline__ int64_t uload_i64(const int64_t* __restrict__ p) {
     return (int64_t)(((uint64_t)hi << 32) | (uint64_t)lo);
 }
 
-// Fold the RW finished row sums of one wave-slab and clear them. Two passes:
-//   1. per row: filter decision, count, argmax, optional outputs (cheap, every lane busy); the kept
-//      s_i are compacted to the front of the wave's own sums slice;
-//   2. exp / log1p / compensated sums over the compacted list only, 64 kept rows per instruction.
-// (With the default cut-off < 1 % of the rows survive: the transcendental work all but vanishes.)
-template <int RW>
-__device__ __noinline__ void ws_epilogue(double* sums, int64_t t, int lane, Acc* acc_io, int64_t n_rows,
-                                         int64_t row_offset, double log_cut, int limit_order, int need_len,
-                                         const int64_t* row_ptr, double* row_logp_out, uint64_t* keep_mask_out,
-                                         int it_begin, int it_end) {
-    // rows [it_begin*64, it_end*64) of the wave-slab are this wave's share; it compacts into the front
-    // of its own share only
-    Acc acc = *acc_io;
-    const int comp_base = it_begin * kWave;
-    int n_comp = 0; // wave-uniform
-    constexpr int U = 8;
-    for (int i0 = it_begin; i0 < it_end; i0 += U) {
-        double s[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) s[u] = sums[(i0 + u) * kWave + lane];
-#pragma unroll
-        for (int u = 0; u < U; ++u) sums[(i0 + u) * kWave + lane] = 0.0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t r = t * RW + (i0 + u) * kWave + lane;
-            const bool valid = r < n_rows;
-            int len = 0;
-            if (need_len && valid) len = (int)(row_ptr[r + 1] - row_ptr[r]);
-            const bool keep = valid && (s[u] >= log_cut) && (limit_order == 0 || len <= limit_order);
-            const unsigned long long m = __ballot(keep);
-            if (m != 0) { // wave-uniform: most 64-row groups have no survivor under the default cut-off
-                if (keep) {
-                    acc.n_kept += 1.0;
-                    if (s[u] > acc.max_logp) { acc.max_logp = s[u]; acc.argmax = (double)(row_offset + r); }
-                    const int pos = comp_base + n_comp +
-                                    (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    sums[pos] = s[u]; // pos <= this row's own slot, already read and cleared above
-                }
-                n_comp += __builtin_popcountll(m);
-            }
-            if (row_logp_out != nullptr && valid) row_logp_out[r] = s[u];
-            if (keep_mask_out != nullptr && lane == 0 && r < n_rows) keep_mask_out[r >> 6] = m;
-        }
-    }
-    int j = 0;
-    for (; j + kWave < n_comp; j += 4 * kWave) { // more than one 64-row batch left: four independent exp chains
-        double sv[4];
-        bool on[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            on[u] = j + u * kWave + lane < n_comp;
-            sv[u] = on[u] ? sums[comp_base + j + u * kWave + lane] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (on[u]) sums[comp_base + j + u * kWave + lane] = 0.0;
-        fold_kept_rows<4>(acc.rare, acc.l1p, acc.n_certain, sv, on);
-    }
-    for (; j < n_comp; j += kWave) {
-        const bool on = j + lane < n_comp;
-        const double sv = on ? sums[comp_base + j + lane] : 0.0;
-        if (on) sums[comp_base + j + lane] = 0.0;
-        fold_kept_row(acc.rare, acc.l1p, acc.n_certain, sv, on);
-    }
-    if (it_begin == 0) sums[RW + lane] = 0.0; // the sink
-    *acc_io = acc;
-}
+// (the slab epilogue -- ws_epilogue -- lives in canopy_device.h: the band-stream kernel folds its slabs with it too)
 
 template <int RW, int D, int ABL>
 __global__ __launch_bounds__(WsCfg<RW>::waves * kWave) void k_ws(const uint4* __restrict__ stream,

@@ -52,6 +52,9 @@ int auto_variant(const canopy_model* m) {
     if (m->n_events <= 2048) return CANOPY_KERNEL_ROWS_LDS;
     // round 2, E = 1e5, every row kept: ROWS 64 us / 113 us at 2e6 / 4e6 rows, WAVE_STREAM 72 / 75 (a ~50 us floor: few
     // wave-slabs, one wave each): the stream kernel from 2.5e6 rows
+    // round 3: the band stream (workgroup-wide slabs) where its 17-bit columns reach: 0.93 against 1.19 ms per pass with s_i
+    // written at config 3 (ensure_layouts falls back to the wave-slab stream for a model the band layout does not fit)
+    if (m->n_events <= bs_max_events() && m->n_rows >= (int64_t)2500000) return CANOPY_KERNEL_BAND_STREAM;
     if (m->n_events <= ws_max_events() && m->n_rows >= (int64_t)2500000) return CANOPY_KERNEL_WAVE_STREAM;
     return CANOPY_KERNEL_ROWS;
 }
@@ -142,6 +145,18 @@ canopy_status build_ws(canopy_ctx* ctx, const canopy_model* m) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     m->ws_state = ok ? 1 : -1;
     if (ok) m->device_bytes += (m->ws_total_chunks + 1) * 1024 + (m->n_ws + 1) * 8;
+    return CANOPY_OK;
+}
+
+canopy_status build_bs(canopy_ctx* ctx, const canopy_model* m, bool explicit_request) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (m->bs_state == 1 || m->bs_state == -1 || (m->bs_state == -2 && !explicit_request)) return CANOPY_OK;
+    bool ok = false;
+    HIP_TRY(ctx, bs_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->nnz, m->n_events, m->max_row_len, explicit_request, &m->d_bs_stream,
+                          &m->d_bs_off, &m->d_bs_used, &m->bs_total_ss, &m->bs_used_ss, &m->n_bs_slabs, &ok, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    m->bs_state = ok ? 1 : (explicit_request ? -1 : -2);
+    if (ok) m->device_bytes += (m->bs_total_ss + 1) * 16384 + (m->n_bs_slabs + 1) * 8 + m->n_bs_slabs * 4;
     return CANOPY_OK;
 }
 
@@ -268,7 +283,7 @@ canopy_status plan_pass(canopy_ctx* ctx, const canopy_model* m, const PSet* P, c
         if (variant == CANOPY_KERNEL_FIXED_SUM && m->max_row_len > fx_max_row_len())
             return fail(ctx, CANOPY_ERR_UNSUPPORTED, "FIXED_SUM needs rows of at most 63 entries");
     } else if (variant != CANOPY_KERNEL_ROWS && variant != CANOPY_KERNEL_ROWS_LDS && variant != CANOPY_KERNEL_WAVE_STREAM &&
-               variant != CANOPY_KERNEL_VALUE_SCATTER) {
+               variant != CANOPY_KERNEL_VALUE_SCATTER && variant != CANOPY_KERNEL_BAND_STREAM) {
         return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
     }
     if (variant == CANOPY_KERNEL_ROWS_LDS && (size_t)m->n_events > rows_lds_table_limit_events())
@@ -302,6 +317,15 @@ canopy_status ensure_layouts(canopy_ctx* ctx, const canopy_model* m, const canop
             if (params->kernel == CANOPY_KERNEL_VALUE_SCATTER)
                 return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a value-scatter stream");
             pl.variant = CANOPY_KERNEL_ROWS;
+        }
+    }
+    if (pl.variant == CANOPY_KERNEL_BAND_STREAM) {
+        canopy_status pst = build_bs(ctx, m, params->kernel == CANOPY_KERNEL_BAND_STREAM);
+        if (pst != CANOPY_OK) return pst;
+        if (m->bs_state != 1) {
+            if (params->kernel == CANOPY_KERNEL_BAND_STREAM)
+                return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a band stream");
+            pl.variant = m->n_events <= ws_max_events() ? CANOPY_KERNEL_WAVE_STREAM : CANOPY_KERNEL_ROWS; // AUTO
         }
     }
     if (pl.variant == CANOPY_KERNEL_WAVE_STREAM) {
@@ -533,6 +557,10 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
     } else if (pl.variant == CANOPY_KERNEL_VALUE_SCATTER) {
         HIP_TRY(ctx, launch_vs_kernel(a, m->d_vs_stream, m->d_vs_off, m->d_vs_slab_row, m->vs_total_chunks, m->n_slabs,
                                       grid, ctx->stream));
+    } else if (pl.variant == CANOPY_KERNEL_BAND_STREAM) {
+        const int need_len = (params->limit_order != 0 && params->limit_order < m->max_row_len) ? 1 : 0;
+        HIP_TRY(ctx, launch_bs_kernel(a, m->d_bs_stream, m->d_bs_off, m->d_bs_used, m->bs_total_ss, m->n_bs_slabs, need_len, grid,
+                                      &n_records, ctx->stream));
     } else if (pl.variant == CANOPY_KERNEL_WAVE_STREAM) {
         const int need_len = (params->limit_order != 0 && params->limit_order < m->max_row_len) ? 1 : 0;
         HIP_TRY(ctx, launch_ws_kernel(a, m->d_ws_stream, m->d_ws_off, m->ws_total_chunks, m->n_ws, need_len, grid,
@@ -604,6 +632,8 @@ canopy_status enqueue_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, cons
 
     if (pl.variant == CANOPY_KERNEL_WAVE_STREAM)
         pl.grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : ws_default_grid(ctx->n_cu, m->n_ws);
+    else if (pl.variant == CANOPY_KERNEL_BAND_STREAM)
+        pl.grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : bs_default_grid(ctx->n_cu, m->n_bs_slabs);
     else if (pl.variant == CANOPY_KERNEL_VALUE_SCATTER)
         pl.grid = ctx->n_blocks_override > 0 ? ctx->n_blocks_override : vs_default_grid(ctx->n_cu, m->n_slabs);
     else if (pl.variant == CANOPY_KERNEL_FILTER_REFINE || pl.variant == CANOPY_KERNEL_FIXED_SUM)

@@ -173,6 +173,8 @@ typedef struct canopy_model_info {
     int64_t algorithmic_bytes;  /* (R+1)*8 + nnz*4 + E*8: compulsory traffic of one sum-only pass */
     int64_t stream_bytes_wide;  /* bytes one pass over the 32-bit form of the slab stream reads (FIXED_SUM, the gathered filter:
                                    4 B per entry in 1 KiB chunks + chunk offsets + the fixed-point table once), 0 without a slab stream */
+    int64_t stream_bytes_exact; /* bytes one pass of the exact all-rows stream kernel reads (the band stream when the model has
+                                   one, else the wave-slab stream; entries + offsets + the logp table once), 0 if neither is built */
 } canopy_model_info;
 
 CANOPY_API canopy_status canopy_model_get_info(const canopy_model* model, canopy_model_info* info);
@@ -244,12 +246,17 @@ enum {
     CANOPY_KERNEL_FILTER_REFINE = 5, /* cut_off > 0, no per-row output: a fast unordered pass flags the rows
                                        that might survive, an exact CSR-order pass recomputes only those.
                                        Reported values are exactly those of the other variants. */
-    CANOPY_KERNEL_FIXED_SUM = 6     /* no per-row output, rows of <= 63 entries: every row summed in 2^-47 fixed point
+    CANOPY_KERNEL_FIXED_SUM = 6,    /* no per-row output, rows of <= 63 entries: every row summed in 2^-47 fixed point
                                        (integer adds commute, so all waves share a slab: no ordering constraint),
                                        exp / log1p taken from that sum (|error| <= L*2^-48 + L*|s|*2^-53, inside the
                                        1e-12 contract); the rows whose keep decision or argmax rank that error could
                                        change are recomputed in exact CSR order. Integer outputs are the canonical ones
                                        bit for bit; AUTO's choice for cut_off = 0 and for cut-offs most rows survive. */
+    CANOPY_KERNEL_BAND_STREAM = 7   /* derived layout: slabs of 16384 rows shared by the 16 waves of a workgroup, entries in
+                                       column-sorted BANDS in which a row appears at most once, a workgroup barrier between
+                                       bands: exact CSR-order sums (per-row output, keep mask, importance) with four times
+                                       denser table gathers than WAVE_STREAM. E <= 131072; AUTO's choice there from 2.5e6
+                                       rows when per-row outputs are asked for (WAVE_STREAM for a model it does not fit). */
 };
 
 CANOPY_API void canopy_quant_params_default(canopy_quant_params* params);

@@ -70,6 +70,8 @@ def test_random_models_every_variant(gpu_ctx, oracle, seed):
         kernels.append(_capi.KERNEL_ROWS_LDS)
     if max_len <= 4095:
         kernels.append(_capi.KERNEL_VALUE_SCATTER)
+    if n_events <= (1 << 17):
+        kernels.append(_capi.KERNEL_BAND_STREAM)
     for kern in kernels:
         got = gpu_ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit_order, kernel=kern,
                                                      flags=_capi.QUANT_ROW_LOGP | _capi.QUANT_KEEP_MASK))
