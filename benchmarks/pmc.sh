@@ -24,8 +24,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        m = re.search(r"(k_fr_filter_q8|k_fr_filter|k_fr_refine|k_fx2|k_fx_sum|k_ws_build|k_fr_build|k_ws|k_rows|k_vs|k_finalize|k_mc|k_batch_rows)", k)
-        if m and m.group(1) in ("k_ws", "k_rows", "k_vs", "k_fr_filter_q8", "k_fr_filter", "k_fr_refine", "k_fx2", "k_fx_sum", "k_mc", "k_batch_rows"):
+        m = re.search(r"(k_fr_filter_q8|k_fr_filter|k_fr_refine|k_fx2|k_fx_sum|k_ws_build|k_fr_build|k_bs_place|k_bs_sort|k_bs_alloc|k_bs|k_ws|k_rows|k_vs|k_finalize|k_mc|k_batch_rows)", k)
+        if m and m.group(1) in ("k_bs", "k_ws", "k_rows", "k_vs", "k_fr_filter_q8", "k_fr_filter", "k_fr_refine", "k_fx2", "k_fx_sum", "k_mc", "k_batch_rows"):
             agg[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in agg.items():
     print("==", k)

@@ -390,7 +390,7 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
         info->stream_bytes = m->ws_total_chunks * 1024 + (m->n_ws + 1) * 8 + (int64_t)m->n_events * 8;
     info->stream_bytes_exact = 0;
     if (m->bs_state == 1)
-        info->stream_bytes_exact = m->bs_used_ss * 16384 + m->n_bs_slabs * 12 + (int64_t)m->n_events * 8;
+        info->stream_bytes_exact = m->bs_used_ss * bs_ss_bytes() + m->n_bs_slabs * 12 + (int64_t)m->n_events * 8;
     else if (m->ws_state == 1)
         info->stream_bytes_exact = m->ws_total_chunks * 1024 + (m->n_ws + 1) * 8 + (int64_t)m->n_events * 8;
     info->algorithmic_bytes = (m->n_rows + 1) * 8 + m->nnz * 4 + (int64_t)m->n_events * 8;

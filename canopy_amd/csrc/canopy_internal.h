@@ -372,6 +372,7 @@ hipError_t launch_ws_kernel(const RowKernelArgs& ra, const uint32_t* stream, con
 // kernels_bs.hip
 int bs_max_events();
 int bs_slab_rows();
+int64_t bs_ss_bytes();
 int bs_default_grid(int n_cu, int64_t n_slabs);
 hipError_t bs_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int64_t nnz, int32_t n_events,
                     int32_t max_row_len, bool accept_padding, uint32_t** d_stream_out, int64_t** d_off_out, int32_t** d_used_out,

@@ -22,8 +22,10 @@
 //     the gathers one superstep ahead, across slab boundaries; a slab ends with every wave folding ITS 1024 rows
 //     (ws_epilogue) between two barriers.
 //
-// Measured at config 3 (benchmarks/proto_bs.hip, the standalone prototype; benchmarks/microbench8.hip, the bare loop): 0.93 ms
-// per pass with every s_i written against 1.19 for the wave-slab stream; bands of 1024 / 4096 slots 0.99 / 0.98.
+// Measured at config 3: 0.93 ms per pass with every s_i written against 1.19 for the wave-slab stream (DESIGN.md 3;
+// benchmarks/microbench8.hip: the bare loop; benchmarks/proto_bs.hip: the standalone prototype -- bands of 1024 / 4096 slots
+// 1.01 / 0.98 there; benchmarks/build_bs_variant.sh builds the library with another geometry: BS_ROWS, BS_WAVES, BS_GPB,
+// BS_WGS -- two workgroups of 8 waves on 8192-row slabs per CU: 1.07).
 // The placement uses LDS atomics: WHICH slot of a band an entry takes can differ from build to build, the sums cannot.
 #include <stdlib.h>
 
@@ -36,11 +38,23 @@ namespace canopy {
 
 namespace {
 
-constexpr int kBsSlabRows = 16384, kBsWaves = 16, kBsThreads = kBsWaves * kWave;
-constexpr int kBsGroupsPerBand = 2;                       // per wave: a barrier follows every 2 adds
-constexpr int kBsBand = 1024 * kBsGroupsPerBand;          // slots per band
-constexpr int kBsFill = 1000 * kBsGroupsPerBand;          // nominal entries per band (slack for the column shares' scatter)
-constexpr int kBsRowBits = 15;                            // 16384 rows + 64 sink slots
+#ifndef BS_ROWS
+#define BS_ROWS 16384
+#endif
+#ifndef BS_WAVES
+#define BS_WAVES 16
+#endif
+#ifndef BS_GPB
+#define BS_GPB 2
+#endif
+#ifndef BS_WGS
+#define BS_WGS 1 // workgroups per CU
+#endif
+constexpr int kBsSlabRows = BS_ROWS, kBsWaves = BS_WAVES, kBsThreads = kBsWaves * kWave;
+constexpr int kBsGroupsPerBand = BS_GPB;                  // per wave: a barrier follows every BS_GPB adds
+constexpr int kBsBand = kWave * kBsWaves * kBsGroupsPerBand; // slots per band
+constexpr int kBsFill = kBsBand * 995 / 1024;             // nominal entries per band (slack for the column shares' scatter)
+constexpr int kBsRowBits = BS_ROWS > 8192 ? 15 : 14;      // the slab's rows + 64 sink slots
 constexpr uint32_t kBsRowMask = (1u << kBsRowBits) - 1;
 constexpr int kBsMaxBands = 8192;                         // per slab (LDS counters of the placement)
 constexpr int kBsSsEntries = kBsThreads * 4;              // entries per superstep (16 KiB)
@@ -94,11 +108,54 @@ __global__ __launch_bounds__(256) void k_bs_place(const int64_t* __restrict__ ro
     __syncthreads();
     uint32_t* out = tmp + ss_off[s] * kBsSsEntries;
     bool ovf = false;
+    const int n_nom = (int)nom;
     for (int64_t r = r0 + threadIdx.x; r < r1 && !ovf; r += 256) {
+        const int64_t kb = row_ptr[r];
+        const int L = (int)(row_ptr[r + 1] - kb);
+        // A row whose last entries share the last nominal bands would open new, nearly empty bands behind them (two per
+        // slab at config 3: a twentieth of the pass): such a row's TRAILING entries are planned backwards from the last
+        // nominal band instead (g: the latest strictly increasing bands at or before the nominal ones), its leading entries
+        // forwards as usual (f), switching where g passes f. Rows of more than 32 entries keep the plain forward rule.
+        int tgt[32];
+        const bool planned = L >= 1 && L <= 32;
+        if (planned) {
+            int f[32], x = -1;
+            for (int k = 0; k < L; ++k) {
+                tgt[k] = (int)(((uint64_t)(uint32_t)col[kb + k] * nom) / n_events);
+                x = tgt[k] > x + 1 ? tgt[k] : x + 1;
+                f[k] = x;
+            }
+            if (f[L - 1] > n_nom - 1 && L <= n_nom) {
+                int g[32];
+                x = n_nom;
+                for (int k = L - 1; k >= 0; --k) { x = tgt[k] < x - 1 ? tgt[k] : x - 1; g[k] = x; }
+                int k0 = -1;
+                for (int k = 0; k < L && k0 < 0; ++k)
+                    if (k == 0 ? g[0] >= 0 : g[k] > f[k - 1]) k0 = k;
+                if (k0 >= 0) {
+                    // ... and an entry that had to move takes a band up to 7 before its latest one (left at the latest, the
+                    // moved entries of all such rows pile into the last two or three bands and overflow them)
+                    const int base = k0 > 0 ? f[k0 - 1] + 1 : 0; // entry k0's earliest band; entry k needs k - k0 bands below it
+                    x = n_nom;
+                    for (int k = L - 1; k >= k0; --k) {
+                        const int hi = tgt[k] < x - 1 ? tgt[k] : x - 1;
+                        int b = hi;
+                        if (hi < tgt[k]) {
+                            const int lo = base + (k - k0);
+                            b = hi - (int)((uint32_t)((uint64_t)(r * 31 + k) * 0x9E3779B97F4A7C15ULL >> 61)); // 0 .. 7
+                            if (b < lo) b = lo;
+                        }
+                        g[k] = b;
+                        x = b;
+                    }
+                    for (int k = 0; k < L; ++k) tgt[k] = k < k0 ? f[k] : g[k];
+                }
+            }
+        }
         int b_prev = -1;
-        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1] && !ovf; ++k) {
+        for (int64_t k = kb; k < kb + L && !ovf; ++k) {
             const uint32_t c = (uint32_t)col[k];
-            int b = (int)(((uint64_t)c * nom) / n_events);
+            int b = planned ? tgt[k - kb] : (int)(((uint64_t)c * nom) / n_events);
             if (b <= b_prev) b = b_prev + 1;
             for (;;) {
                 if (b >= n_alloc) { ovf = true; break; }
@@ -212,7 +269,7 @@ __device__ __forceinline__ void bs_epilogue(double* sums, double* pend, int& n_p
 }
 
 template <bool ROWS, bool MASK>
-__global__ __launch_bounds__(kBsThreads) void k_bs(const uint4* __restrict__ stream, const int64_t* __restrict__ ss_off,
+__global__ __launch_bounds__(kBsThreads) __attribute__((amdgpu_waves_per_eu(kBsWaves * BS_WGS / 4))) void k_bs(const uint4* __restrict__ stream, const int64_t* __restrict__ ss_off,
                                                    const int32_t* __restrict__ ss_used, const double* __restrict__ logp,
                                                    const int64_t* __restrict__ row_ptr, BsScalars sc, double* __restrict__ block_partials,
                                                    double* __restrict__ row_logp_out, uint64_t* __restrict__ keep_mask_out) {
@@ -242,35 +299,46 @@ __global__ __launch_bounds__(kBsThreads) void k_bs(const uint4* __restrict__ str
     }
     int64_t s = (int64_t)blockIdx.x;
     if (s < sc.n_slabs) {
-        uint4 e_cur, e_next;
-        BS_NEXT(e_cur)
-        double v[4] = {logp[e_cur.x >> kBsRowBits], logp[e_cur.y >> kBsRowBits], logp[e_cur.z >> kBsRowBits], logp[e_cur.w >> kBsRowBits]};
-        BS_NEXT(e_next)
+        // Three register sets in rotation (entries + gathered values), the loop body written out three times: a copy
+        // "cur = next" at the end of a single body makes the compiler wait for EVERY load in flight each iteration (the
+        // gathers just issued, the stream load behind them), i.e. one memory latency per superstep.
+        uint4 e0, e1, e2;
+        double v0[4], v1[4], v2[4];
+        BS_NEXT(e0)
+        v0[0] = logp[e0.x >> kBsRowBits]; v0[1] = logp[e0.y >> kBsRowBits]; v0[2] = logp[e0.z >> kBsRowBits]; v0[3] = logp[e0.w >> kBsRowBits];
+        BS_NEXT(e1)
         int rem = __builtin_amdgcn_readfirstlane(ss_used[s]);
-        for (;;) {
-            while (rem == 0) { // slab finished (or without entries): every wave folds ITS 1024 rows, then the next slab
-                bs_barrier();
-                bs_epilogue<ROWS, MASK>(sums, pend, n_pend, s, wave, lane, acc, sc, row_ptr, row_logp_out, keep_mask_out);
-                bs_barrier();
-                s += G;
-                if (s >= sc.n_slabs) break;
-                rem = __builtin_amdgcn_readfirstlane(ss_used[s]);
-            }
-            if (s >= sc.n_slabs) break;
-            const uint4 e_add = e_cur;
-            const double a[4] = {v[0], v[1], v[2], v[3]};
-            e_cur = e_next; // the next superstep: its gathers go out now, its adds happen in the next iteration
-            v[0] = logp[e_cur.x >> kBsRowBits]; v[1] = logp[e_cur.y >> kBsRowBits];
-            v[2] = logp[e_cur.z >> kBsRowBits]; v[3] = logp[e_cur.w >> kBsRowBits];
-            BS_NEXT(e_next)
-            const uint32_t r4[4] = {e_add.x & kBsRowMask, e_add.y & kBsRowMask, e_add.z & kBsRowMask, e_add.w & kBsRowMask};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                __hip_atomic_fetch_add(&sums[r4[j]], a[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if ((j + 1) % kBsGroupsPerBand == 0) bs_barrier(); // the band is complete: its rows may appear again
-            }
-            --rem;
+        // EA / VA: the superstep whose adds happen now (its gathers went out one step ago); EB: loaded, its gathers go out now
+        // into VB; EC: the stream load of the superstep after that
+#define BS_STEP(EA, VA, EB, VB, EC)                                                                                      \
+        {                                                                                                                \
+            while (rem == 0) { /* slab finished (or without entries): every wave folds ITS 1024 rows, then the next slab */ \
+                bs_barrier();                                                                                            \
+                bs_epilogue<ROWS, MASK>(sums, pend, n_pend, s, wave, lane, acc, sc, row_ptr, row_logp_out, keep_mask_out); \
+                bs_barrier();                                                                                            \
+                s += G;                                                                                                  \
+                if (s >= sc.n_slabs) break;                                                                              \
+                rem = __builtin_amdgcn_readfirstlane(ss_used[s]);                                                        \
+            }                                                                                                            \
+            if (s >= sc.n_slabs) break;                                                                                  \
+            /* (all four gathers and the stream load first: taking turns -- one gather, one add -- was measured slower,     \
+               0.879 against 0.795 ms for the sum-only pass at config 3) */                                               \
+            VB[0] = logp[EB.x >> kBsRowBits]; VB[1] = logp[EB.y >> kBsRowBits];                                          \
+            VB[2] = logp[EB.z >> kBsRowBits]; VB[3] = logp[EB.w >> kBsRowBits];                                          \
+            BS_NEXT(EC)                                                                                                  \
+            const uint32_t r4[4] = {EA.x & kBsRowMask, EA.y & kBsRowMask, EA.z & kBsRowMask, EA.w & kBsRowMask};         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+                __hip_atomic_fetch_add(&sums[r4[j]], VA[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);             \
+                if ((j + 1) % kBsGroupsPerBand == 0) bs_barrier(); /* the band is complete: its rows may appear again */ \
+            }                                                                                                            \
+            --rem;                                                                                                       \
         }
+        for (;;) {
+            BS_STEP(e0, v0, e1, v1, e2)
+            BS_STEP(e1, v1, e2, v2, e0)
+            BS_STEP(e2, v2, e0, v0, e1)
+        }
+#undef BS_STEP
     }
 #undef BS_NEXT
     if (n_pend > 0) fold_kept_row(acc.rare, acc.l1p, acc.n_certain, lane < n_pend ? pend[lane] : 0.0, lane < n_pend); // (wave-uniform)
@@ -296,9 +364,10 @@ __global__ __launch_bounds__(kBsThreads) void k_bs(const uint4* __restrict__ str
 
 int bs_max_events() { return 1 << (32 - kBsRowBits); }
 int bs_slab_rows() { return kBsSlabRows; }
+int64_t bs_ss_bytes() { return (int64_t)kBsSsEntries * 4; }
 
 int bs_default_grid(int n_cu, int64_t n_slabs) {
-    int64_t g = n_slabs < n_cu ? n_slabs : n_cu;
+    int64_t g = n_slabs < (int64_t)n_cu * BS_WGS ? n_slabs : (int64_t)n_cu * BS_WGS;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -410,7 +479,7 @@ hipError_t launch_bs_kernel(const RowKernelArgs& ra, const uint32_t* stream, con
     const bool rows = ra.row_logp_out != nullptr, mask = ra.keep_mask_out != nullptr;
 #define BS_LAUNCH(R, M)                                                                                                                  \
     {                                                                                                                                    \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bs<R, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bs<R, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / BS_WGS); \
         if (e != hipSuccess) return e;                                                                                                   \
         hipLaunchKernelGGL((k_bs<R, M>), dim3(grid), dim3(kBsThreads), kBsLdsBytes, s, reinterpret_cast<const uint4*>(stream), ss_off, ss_used, \
                            ra.logp, ra.row_ptr, sc, ra.block_partials, ra.row_logp_out, ra.keep_mask_out);                               \

@@ -156,7 +156,7 @@ canopy_status build_bs(canopy_ctx* ctx, const canopy_model* m, bool explicit_req
                           &m->d_bs_off, &m->d_bs_used, &m->bs_total_ss, &m->bs_used_ss, &m->n_bs_slabs, &ok, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     m->bs_state = ok ? 1 : (explicit_request ? -1 : -2);
-    if (ok) m->device_bytes += (m->bs_total_ss + 1) * 16384 + (m->n_bs_slabs + 1) * 8 + m->n_bs_slabs * 4;
+    if (ok) m->device_bytes += (m->bs_total_ss + 1) * bs_ss_bytes() + (m->n_bs_slabs + 1) * 8 + m->n_bs_slabs * 4;
     return CANOPY_OK;
 }
 

@@ -173,3 +173,41 @@ def test_pipelined_passes_over_alternating_models(gpu_ctx, oracle):
         gpu_ctx.synchronize()
         for m in models:
             m.close()
+
+
+def test_band_stream_is_auto_for_per_row_output_and_takes_long_rows(gpu_ctx, oracle):
+    """The band stream (kernels_bs.hip): AUTO's exact all-rows kernel from 2.5e6 rows (E <= 131072) -- every s_i and the keep
+    mask of a 3e6-row model (184 slabs, the last one partial) bit for bit, limit_order below the longest row (the epilogue
+    reads row lengths); rows of up to 300 entries (the builder's plain forward rule beyond 32 entries; a row needs as many
+    bands as it has entries) and a column every row contains; beyond 2^17 basic events the variant is refused."""
+    import canopy_amd
+    from canopy_amd import _capi, default_params
+    seed, n, e = 20250704, 3_000_000, 50_000
+    model = gpu_ctx.synthetic(seed, n, e, 6)
+    p = canopy_amd.synthetic_probabilities(seed, e)
+    model.set_probabilities(p)
+    row_ptr, col = model.download()
+    for cut_off, limit in ((1e-8, 20), (0.0, 7)):
+        want = oracle.quantify(row_ptr, col, p, cut_off=cut_off, limit_order=limit, n_threads=4)
+        got = gpu_ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit, flags=_capi.QUANT_ROW_LOGP | _capi.QUANT_KEEP_MASK))
+        assert gpu_ctx.last_kernel_variant() == _capi.KERNEL_BAND_STREAM
+        assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row) and got.max_logp == want.max_logp
+        assert abs(got.rare_event - want.rare_event) <= 1e-12 * want.rare_event and abs(got.mcub - want.mcub) <= 1e-12 * want.mcub
+        assert np.array_equal(gpu_ctx.fetch_row_logp(model), want.row_logp)
+        assert np.array_equal(gpu_ctx.fetch_keep_mask(model), want.keep_mask)
+    model.close()
+    # long rows, a hot column
+    rng = np.random.default_rng(77)
+    rows = random_rows(rng, 40_000, 0, 3000, 300, always=(1500,))
+    rp, ci = csr_from_rows(rows)
+    pp = 10.0 ** rng.uniform(-3, 0, size=3000)
+    check_against_oracle(gpu_ctx, oracle, rp, ci, pp, 3000, 1e-30, 0)
+    # too wide for the 17-bit columns of the band stream: an explicit request is refused, AUTO takes another kernel
+    wide = gpu_ctx.synthetic(seed, 50_000, 140_000, 6)
+    wide.set_probabilities(canopy_amd.synthetic_probabilities(seed, 140_000))
+    with pytest.raises(_capi.CanopyError) as err:
+        gpu_ctx.quantify(wide, default_params(kernel=_capi.KERNEL_BAND_STREAM, flags=_capi.QUANT_ROW_LOGP))
+    assert err.value.status == _capi.ERR_UNSUPPORTED
+    gpu_ctx.quantify(wide, default_params(flags=_capi.QUANT_ROW_LOGP))
+    assert gpu_ctx.last_kernel_variant() != _capi.KERNEL_BAND_STREAM
+    wide.close()
