@@ -53,8 +53,10 @@ int auto_variant(const canopy_model* m) {
     // round 2, E = 1e5, every row kept: ROWS 64 us / 113 us at 2e6 / 4e6 rows, WAVE_STREAM 72 / 75 (a ~50 us floor: few
     // wave-slabs, one wave each): the stream kernel from 2.5e6 rows
     // round 3: the band stream (workgroup-wide slabs) where its 17-bit columns reach: 0.93 against 1.19 ms per pass with s_i
-    // written at config 3 (ensure_layouts falls back to the wave-slab stream for a model the band layout does not fit)
-    if (m->n_events <= bs_max_events() && m->n_rows >= (int64_t)2500000) return CANOPY_KERNEL_BAND_STREAM;
+    // written at config 3 (ensure_layouts falls back to the wave-slab stream for a model the band layout does not fit); a
+    // ~44 us floor (one slab = one workgroup): level with ROWS at ~1.4e6 rows for E = 1e5, ~2e6 for E = 1e4
+    // (benchmarks/bs_small.py: 2e6 rows, s_i written: ROWS 64 / 49 us, WAVE_STREAM 57 / 52, BAND_STREAM 49 / 48)
+    if (m->n_events <= bs_max_events() && m->n_rows >= (int64_t)2000000) return CANOPY_KERNEL_BAND_STREAM;
     if (m->n_events <= ws_max_events() && m->n_rows >= (int64_t)2500000) return CANOPY_KERNEL_WAVE_STREAM;
     return CANOPY_KERNEL_ROWS;
 }

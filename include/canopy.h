@@ -255,7 +255,7 @@ enum {
     CANOPY_KERNEL_BAND_STREAM = 7   /* derived layout: slabs of 16384 rows shared by the 16 waves of a workgroup, entries in
                                        column-sorted BANDS in which a row appears at most once, a workgroup barrier between
                                        bands: exact CSR-order sums (per-row output, keep mask, importance) with four times
-                                       denser table gathers than WAVE_STREAM. E <= 131072; AUTO's choice there from 2.5e6
+                                       denser table gathers than WAVE_STREAM. E <= 131072; AUTO's choice there from 2e6
                                        rows when per-row outputs are asked for (WAVE_STREAM for a model it does not fit). */
 };
 

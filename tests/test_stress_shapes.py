@@ -176,7 +176,7 @@ def test_pipelined_passes_over_alternating_models(gpu_ctx, oracle):
 
 
 def test_band_stream_is_auto_for_per_row_output_and_takes_long_rows(gpu_ctx, oracle):
-    """The band stream (kernels_bs.hip): AUTO's exact all-rows kernel from 2.5e6 rows (E <= 131072) -- every s_i and the keep
+    """The band stream (kernels_bs.hip): AUTO's exact all-rows kernel from 2e6 rows (E <= 131072) -- every s_i and the keep
     mask of a 3e6-row model (184 slabs, the last one partial) bit for bit, limit_order below the longest row (the epilogue
     reads row lengths); rows of up to 300 entries (the builder's plain forward rule beyond 32 entries; a row needs as many
     bands as it has entries) and a column every row contains; beyond 2^17 basic events the variant is refused."""
