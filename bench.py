@@ -327,11 +327,27 @@ def main():
             collective = "ncclAllReduce of %d B issued by libcanopy.so (canopy_comm, RCCL %d, collectives %s)" % (
                 world * 64, comm.rccl_version(), args.comm_mode)
         else:
+            # torch's own collective instead: RCCL ("nccl") first; if its communicator cannot be set up either (probed with
+            # one all-reduce, the decision taken by all ranks together), gloo -- slow, but the run completes and says so
             backend = args.rehearse_backend or "nccl"
-            torch_group = dist.new_group(backend=backend)
+            dog.arm("torch.distributed fallback group (%s)" % backend)
+            err2 = ""
+            try:
+                torch_group = dist.new_group(backend=backend)
+                probe = torch.ones(1, dtype=torch.float64, device="cuda:%d" % local_rank)
+                dist.all_reduce(probe, group=torch_group)
+                torch.cuda.synchronize()
+                ok_probe = int(probe.item()) == world
+            except Exception as e:  # noqa: BLE001
+                err2, ok_probe = repr(e), False
+            if not all_ok(ok_probe):
+                sys.stderr.write("[bench] torch.distributed backend %s failed (%s): falling back to gloo\n" % (backend, err2))
+                backend = "gloo"
+                torch_group = dist.new_group(backend=backend)
+            dog.disarm()
             comb = ShardCombiner(ctx=ctx, group=torch_group)
             collective = "torch.distributed all_reduce of %d B (%s)%s" % (world * 64, backend,
-                                                                         " [fallback: %s]" % err if err else "")
+                                                                         " [fallback: %s %s]" % (err, err2) if (err or err2) else "")
 
     # ---- the model: this rank's shard ----
     p = canopy_amd.synthetic_probabilities(SEED, args.events)
