@@ -75,17 +75,28 @@ __device__ __forceinline__ void bs_barrier() { // LDS drained, then the workgrou
 }
 
 // ---- builder ------------------------------------------------------------------------------------------------------
-// supersteps allotted to a slab: nominal bands + an eighth + one per entry of the longest row (a row of L entries needs L
-// different bands) + 4
-__global__ __launch_bounds__(256) void k_bs_alloc(const int64_t* __restrict__ row_ptr, int64_t n_rows, int64_t n_slabs, int max_row_len,
+// supersteps allotted to a slab: nominal bands + an eighth + one per entry of the slab's longest row (a row of L entries
+// needs L different bands) + 4. One workgroup per slab (the longest row of THIS slab: one row of thousands of entries
+// somewhere in a large model must not inflate every slab's allotment).
+__global__ __launch_bounds__(256) void k_bs_alloc(const int64_t* __restrict__ row_ptr, int64_t n_rows, int64_t n_slabs,
                                                   int64_t* __restrict__ ss, int* __restrict__ too_many) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_slabs) return;
+    __shared__ int s_max;
+    const int64_t s = blockIdx.x;
     const int64_t r0 = s * kBsSlabRows, r1 = r0 + kBsSlabRows < n_rows ? r0 + kBsSlabRows : n_rows;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    int64_t mx = 0;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const int64_t len = row_ptr[r + 1] - row_ptr[r];
+        mx = len > mx ? len : mx;
+    }
+    atomicMax(&s_max, (int)(mx > (int64_t)kBsMaxBands ? (int64_t)kBsMaxBands : mx));
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     const int64_t nnz = row_ptr[r1] - row_ptr[r0];
     int64_t nom = (nnz + kBsFill - 1) / kBsFill;
     if (nom < 1) nom = 1;
-    const int64_t alloc = nom + nom / 8 + max_row_len + 4;
+    const int64_t alloc = nom + nom / 8 + s_max + 4;
     if (alloc > kBsMaxBands) atomicExch(too_many, 1);
     ss[s] = (alloc + kBsBandsPerSs - 1) / kBsBandsPerSs;
 }
@@ -424,8 +435,8 @@ hipError_t bs_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 2 * sizeof(int), s);
     if (e == hipSuccess) e = hipMemsetAsync(d_off, 0, sizeof(int64_t), s);
     if (e != hipSuccess) return bail(e);
-    hipLaunchKernelGGL(k_bs_alloc, dim3((unsigned)((n_slabs + 255) / 256)), dim3(256), 0, s, d_row_ptr, n_rows, n_slabs, (int)max_row_len,
-                       d_off + 1, d_flags);
+    (void)max_row_len;
+    hipLaunchKernelGGL(k_bs_alloc, dim3((unsigned)n_slabs), dim3(256), 0, s, d_row_ptr, n_rows, n_slabs, d_off + 1, d_flags);
     e = hipGetLastError();
     if (e == hipSuccess) e = scan_inclusive_i64(d_off + 1, n_slabs, s);
     int flags[2] = {0, 0};

@@ -196,8 +196,24 @@ def test_band_stream_is_auto_for_per_row_output_and_takes_long_rows(gpu_ctx, ora
         assert np.array_equal(gpu_ctx.fetch_row_logp(model), want.row_logp)
         assert np.array_equal(gpu_ctx.fetch_keep_mask(model), want.keep_mask)
     model.close()
-    # long rows, a hot column
+    # ONE row of 1500 entries somewhere in those 3e6: only its slab gets the extra bands, AUTO still takes the band stream
     rng = np.random.default_rng(77)
+    i = 1_234_567
+    long_row = np.sort(rng.choice(e, size=1500, replace=False)).astype(np.int32)
+    lens = np.diff(row_ptr)
+    lens[i] = 1500
+    rp2 = np.zeros(n + 1, dtype=np.int64)
+    rp2[1:] = np.cumsum(lens)
+    col2 = np.concatenate([col[:row_ptr[i]], long_row, col[row_ptr[i + 1]:]])
+    model = gpu_ctx.upload(rp2, col2, e)
+    model.set_probabilities(p)
+    want = oracle.quantify(rp2, col2, p, cut_off=1e-8, limit_order=0, n_threads=4)
+    got = gpu_ctx.quantify(model, default_params(cut_off=1e-8, limit_order=0, flags=_capi.QUANT_ROW_LOGP))
+    assert gpu_ctx.last_kernel_variant() == _capi.KERNEL_BAND_STREAM
+    assert got.n_kept == int(want.n_kept) and got.argmax_row == int(want.argmax_row)
+    assert np.array_equal(gpu_ctx.fetch_row_logp(model), want.row_logp)
+    model.close()
+    # long rows, a hot column
     rows = random_rows(rng, 40_000, 0, 3000, 300, always=(1500,))
     rp, ci = csr_from_rows(rows)
     pp = 10.0 ** rng.uniform(-3, 0, size=3000)
