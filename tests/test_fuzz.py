@@ -151,6 +151,27 @@ def test_random_ticketed_sequences(gpu_ctx, oracle, seed):
             d["m"].close()
 
 
+@pytest.mark.parametrize("seed", range(max(2, int(os.environ.get("CANOPY_FUZZ_SEEDS", "24")) // 4)))
+def test_random_medium_models_every_variant(gpu_ctx, oracle, seed):
+    """Models of 5e4 .. 5e5 rows of the synthetic family (several slabs of every layout, full bands and chunks, a partial last
+    slab) with random width, row length, probabilities and filters: every variant against the oracle, per-row sums and keep
+    masks bit for bit."""
+    from test_gpu_parity import check_against_oracle
+    rng = np.random.default_rng(7000 + seed)
+    n_rows = int(rng.integers(50_000, 500_000))
+    n_events = int(rng.choice([300, 3000, 30_000, 100_000, 131_072, 200_000]))
+    avg = int(rng.choice([2, 3, 6, 9]))
+    row_ptr, col = oracle.synth_csr(int(rng.integers(1, 1 << 30)), n_rows, n_events, avg, n_threads=4)
+    kind = rng.integers(0, 3)
+    p = 10.0 ** rng.uniform(-8, 0, size=n_events) if kind == 0 else (rng.uniform(0.0, 1.0, size=n_events) if kind == 1 else 10.0 ** rng.uniform(-3, -1, size=n_events))
+    if rng.random() < 0.3:
+        p[rng.integers(0, n_events)] = 1.0
+        p[rng.integers(0, n_events)] = 0.0
+    cut_off = float(rng.choice([0.0, 1e-12, 1e-8, 1e-4]))
+    limit_order = int(rng.choice([0, 3, 20]))
+    check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, cut_off, limit_order, row_offset=int(rng.integers(0, 1000)))
+
+
 def random_dag(rng):
     from canopy_amd import _capi as c
     n_events = int(rng.choice([1, 2, 5, 17, 64, 80]))
