@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_bs_place(const int64_t* __restrict__ ro
         const int64_t kb = row_ptr[r];
         const int L = (int)(row_ptr[r + 1] - kb);
         // A row whose last entries share the last nominal bands would open new, nearly empty bands behind them (two per
-        // slab at config 3: a twentieth of the pass): such a row's TRAILING entries are planned backwards from the last
+        // slab at config 3: 4 % of the stream, ~1 % of the pass -- sparse bands are cheap): such a row's TRAILING entries are planned backwards from the last
         // nominal band instead (g: the latest strictly increasing bands at or before the nominal ones), its leading entries
         // forwards as usual (f), switching where g passes f. Rows of more than 32 entries keep the plain forward rule.
         int tgt[32];
