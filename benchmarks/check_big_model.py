@@ -56,5 +56,25 @@ print("oracle quantify (cut_off 0) s", time.time() - t0, int(w0.n_kept), int(w0.
 ok0 = got0.n_kept == int(w0.n_kept) and got0.argmax_row == int(w0.argmax_row) and got0.max_logp == w0.max_logp \
       and abs(got0.rare_event - w0.rare_event) <= 1e-12 * w0.rare_event and abs(got0.mcub - w0.mcub) <= 1e-12 * w0.mcub
 print("MATCH" if ok0 else "MISMATCH", "(cut_off 0)")
+# K1 as stated on the same model: every s_i written (AUTO -> the band stream), all of them against the oracle's, bit for bit
+from canopy_amd import _capi
+prm_r = canopy_amd.default_params(flags=_capi.QUANT_ROW_LOGP | _capi.QUANT_KEEP_MASK)
+got_r = ctx.quantify(m, prm_r)
+for _ in range(2):
+    ctx.quantify_async(m, prm_r)
+ctx.synchronize()
+t0 = time.time()
+for _ in range(3):
+    ctx.quantify_async(m, prm_r)
+ctx.synchronize()
+dt_r = (time.time() - t0) / 3
+rows_gpu = ctx.fetch_row_logp(m)
+mask_gpu = ctx.fetch_keep_mask(m)
+print("gpu per-row output: variant", ctx.last_kernel_variant(), "ms per pass %.3f" % (dt_r * 1e3), got_r.n_kept, got_r.argmax_row, flush=True)
+t0 = time.time()
+wr = oracle_py.quantify(rp, col, p, n_threads=cores, want_rows=True)
+print("oracle quantify with rows s", time.time() - t0, flush=True)
+ok_r = np.array_equal(rows_gpu, wr.row_logp) and np.array_equal(mask_gpu, wr.keep_mask) and got_r.n_kept == int(wr.n_kept)
+print("MATCH" if ok_r else "MISMATCH", "(every s_i and the keep mask, %d rows)" % len(rows_gpu), flush=True)
 info = m.info()
-print("device_bytes", info.device_bytes, "rows", info.n_rows, "nnz", info.nnz)
+print("device_bytes", info.device_bytes, "rows", info.n_rows, "nnz", info.nnz, "stream_bytes_exact", info.stream_bytes_exact)
