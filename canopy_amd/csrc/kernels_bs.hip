@@ -78,8 +78,8 @@ __device__ __forceinline__ void bs_barrier() { // LDS drained, then the workgrou
 // supersteps allotted to a slab: nominal bands + an eighth + one per entry of the slab's longest row (a row of L entries
 // needs L different bands) + 4. One workgroup per slab (the longest row of THIS slab: one row of thousands of entries
 // somewhere in a large model must not inflate every slab's allotment).
-__global__ __launch_bounds__(256) void k_bs_alloc(const int64_t* __restrict__ row_ptr, int64_t n_rows, int64_t n_slabs,
-                                                  int64_t* __restrict__ ss, int* __restrict__ too_many) {
+__global__ __launch_bounds__(256) void k_bs_alloc(const int64_t* __restrict__ row_ptr, int64_t n_rows, int64_t* __restrict__ ss,
+                                                  int* __restrict__ too_many) {
     __shared__ int s_max;
     const int64_t s = blockIdx.x;
     const int64_t r0 = s * kBsSlabRows, r1 = r0 + kBsSlabRows < n_rows ? r0 + kBsSlabRows : n_rows;
@@ -436,7 +436,7 @@ hipError_t bs_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     if (e == hipSuccess) e = hipMemsetAsync(d_off, 0, sizeof(int64_t), s);
     if (e != hipSuccess) return bail(e);
     (void)max_row_len;
-    hipLaunchKernelGGL(k_bs_alloc, dim3((unsigned)n_slabs), dim3(256), 0, s, d_row_ptr, n_rows, n_slabs, d_off + 1, d_flags);
+    hipLaunchKernelGGL(k_bs_alloc, dim3((unsigned)n_slabs), dim3(256), 0, s, d_row_ptr, n_rows, d_off + 1, d_flags);
     e = hipGetLastError();
     if (e == hipSuccess) e = scan_inclusive_i64(d_off + 1, n_slabs, s);
     int flags[2] = {0, 0};

@@ -113,8 +113,6 @@ hipError_t scan_inclusive(int64_t* data, int64_t n, hipStream_t s) {
     return e != hipSuccess ? e : e2;
 }
 
-constexpr int kMaxSynthLen = 32;
-
 __global__ __launch_bounds__(256) void k_synth_cols(uint64_t key_col, int64_t first_row, int64_t n_rows,
                                                     uint32_t n_events, const int64_t* __restrict__ row_ptr,
                                                     int32_t* col_idx) {

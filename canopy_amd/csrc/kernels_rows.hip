@@ -37,13 +37,6 @@ struct RowsLds {
     }
 };
 
-__device__ __forceinline__ int64_t uload_row(const int64_t* __restrict__ p) {
-    const int64_t v = *p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | (uint64_t)lo);
-}
-
 struct RowsFold { CSum rare, l1p; double n_certain; };
 // exp / log1p / compensated sums for 64 queued kept rows (not inlined: keeps the transcendental
 // code's registers out of the streaming loop)

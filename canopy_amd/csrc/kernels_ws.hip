@@ -31,7 +31,6 @@ namespace canopy {
 namespace {
 
 constexpr int kRowBits = 13;
-constexpr uint32_t kRowMask = (1u << kRowBits) - 1;
 constexpr int kGroup = 64;
 constexpr int kChunk = 256; // entries per chunk (one uint4 per lane)
 
