@@ -21,7 +21,8 @@
 //           sums, count, argmax, keep mask. No row that survives exactly can be missed (its s~ is within
 //           1e-13 of s >= log(cut_off)), and no reported value comes from pass A.
 //
-// Per-row log-probability output needs every s_i exactly and therefore uses the WAVE_STREAM kernel.
+// Per-row log-probability output needs every s_i exactly and therefore uses the exact stream kernels (kernels_bs.hip,
+// kernels_ws.hip).
 #include <stdlib.h>
 
 #include "canopy_device.h"
