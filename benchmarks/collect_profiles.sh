@@ -15,6 +15,7 @@ cp $O/${T}_bench.json profiles/${T}_bench_n1.json
 cp $O/${T}_bench_mc.json profiles/${T}_bench_mc_n1.json
 cp $O/${T}_batch_bench.jsonl profiles/${T}_batch_bench.jsonl
 cp $O/${T}_n2_rehearsal.json profiles/${T}_bench_n2_launcher_rehearsal.json
+[ -s $O/${T}_bench_n2_shim.json ] && cp $O/${T}_bench_n2_shim.json profiles/${T}_bench_n2_shim_rehearsal.json
 for f in shard2 shard2_serial shard4 shard4_serial shard8 shard8_serial shard8_rccl shard8_rccl_serial serial; do python3 -c "
 import json
 d=json.load(open('$O/${T}_$f.json')); r=d['roofline']

@@ -20,4 +20,5 @@ PMC_SCRIPT=benchmarks/bench_mc.py PMC_ARGS="--steps 1" bash benchmarks/pmc.sh "$
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_stats_mc" -o mc -- python3 "$R/benchmarks/bench_mc.py" --steps 2 > "$O/${TAG}_stats_mc.log" 2>&1 || echo "mc stats rc=$?"
 cd "$R"
+bash benchmarks/bench_n2_shim.sh 2 > "$O/${TAG}_bench_n2_shim.json" 2> "$O/${TAG}_bench_n2_shim.err" || echo "n2 shim rc=$?"
 echo evidence_all done
