@@ -701,9 +701,14 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8o(const uint32_t* __
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int64_t G = (int64_t)gridDim.x;
+    // A CONTIGUOUS block of slabs per workgroup (the first n_slabs % G workgroups take one more), not slabs blockIdx, blockIdx + G,
+    // ...: 1 % faster at config 3 (0.3276 against 0.3313 ms per step, three alternated runs each on one box; giving every XCD a
+    // contiguous eighth of the model instead: 0.3322, no better than round-robin)
+    const int64_t q_wg = n_slabs / G, r_wg = n_slabs % G, b_wg = (int64_t)blockIdx.x;
+    const int64_t s_begin = b_wg * q_wg + (b_wg < r_wg ? b_wg : r_wg), s_end = s_begin + q_wg + (b_wg < r_wg ? 1 : 0);
     Q8Chunk q[U];
 #define FRO_FIRST_CHUNKS(SLAB)                                                                      \
-    if ((SLAB) < n_slabs) {                                                                         \
+    if ((SLAB) < s_end) {                                                                         \
         const int64_t f0 = fr_uload(fr_off + (SLAB));                                               \
         const int64_t f1 = __builtin_amdgcn_readfirstlane(exc[(SLAB)]) != 0 ? f0 : fr_uload(fr_off + (SLAB) + 1); \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                             \
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8o(const uint32_t* __
             q[u] = q8_load_chunk<true>(stream, cbase, c < f1 ? c : total_chunks, lane);             \
         }                                                                                           \
     }
-    FRO_FIRST_CHUNKS((int64_t)blockIdx.x)
+    FRO_FIRST_CHUNKS(s_begin)
     for (int i = tid; i < 2 * kQ8oBufWords; i += kQ8Threads) bufs[i] = 0u;
     {
         const uint4* src = reinterpret_cast<const uint4*>(q8);
@@ -726,8 +731,8 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8o(const uint32_t* __
     bool all_count = false;
     const unsigned long long below = (1ULL << lane) - 1ULL;
     int it = 0;
-    for (int64_t s = (int64_t)blockIdx.x;; s += G, ++it) {
-        const bool have = s < n_slabs;
+    for (int64_t s = s_begin;; s += 1, ++it) {
+        const bool have = s < s_end;
         // an exception slab of the 24-bit form: no chunk is read, every row goes to the exact pass
         const bool all_rows = have && __builtin_amdgcn_readfirstlane(exc[have ? s : 0]) != 0;
         if (s_emit >= 0) { // ---- the list of slab s_emit: this wave's candidates behind those of the waves before it
@@ -815,7 +820,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8o(const uint32_t* __
                 (void)in_q;
             }
 #undef Q8O_HALF
-            FRO_FIRST_CHUNKS(s + G) // the next slab's stream starts before this slab's barrier (always into q)
+            FRO_FIRST_CHUNKS(s + 1) // the next slab's stream starts before this slab's barrier (always into q)
         }
         s_emit = s_count;           // (its counts are published once this iteration's barrier is passed)
         s_count = have ? s : -1;
@@ -1468,7 +1473,7 @@ __global__ __launch_bounds__(kFx2Waves * kWave) void k_fx2(const uint4* __restri
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    const int64_t G = (int64_t)gridDim.x;
+    const int64_t G = (int64_t)gridDim.x; // (slabs blockIdx, blockIdx + G, ...: contiguous blocks per workgroup, which pay in k_fr_filter_q8o, cost 1 % here)
     const bool adder = wave < ADD;
     uint4 q[U], q2[U];
 #define FX2_FIRST_CHUNKS(SLAB)                                                                      \
