@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV of `bench.py --shard-of 8 ...`: durations of the pass's kernels and the period
-between consecutive filter launches over the last passes. usage: shard_timeline.py <kernel_trace.csv> [label]"""
+between consecutive filter launches over the last passes. usage: shard_timeline.py <kernel_trace.csv> [label] [passes to skip at the end]"""
 import csv
 import sys
 
@@ -11,6 +11,9 @@ for r in csv.DictReader(open(sys.argv[1])):
     if tag:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), tag))
 rows.sort()
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # passes to leave out at the end (bench.py's serial probe)
+if skip:
+    rows = rows[:-3 * skip]
 rows = rows[-3 * 150:]
 label = sys.argv[2] if len(sys.argv) > 2 else ""
 for tag in "FRZ":
