@@ -187,6 +187,10 @@ def test_band_stream_is_auto_for_per_row_output_and_takes_long_rows(gpu_ctx, ora
     p = canopy_amd.synthetic_probabilities(seed, e)
     model.set_probabilities(p)
     row_ptr, col = model.download()
+    assert model.info().stream_bytes_exact == 0
+    model.prepare(_capi.KERNEL_BAND_STREAM)  # (the layout can be built ahead of the first pass)
+    per_row = model.info().stream_bytes_exact / n
+    assert 24.0 < per_row < 30.0, per_row  # 4 B per entry, avg 6 entries per row, a few per cent of padding
     for cut_off, limit in ((1e-8, 20), (0.0, 7)):
         want = oracle.quantify(row_ptr, col, p, cut_off=cut_off, limit_order=limit, n_threads=4)
         got = gpu_ctx.quantify(model, default_params(cut_off=cut_off, limit_order=limit, flags=_capi.QUANT_ROW_LOGP | _capi.QUANT_KEEP_MASK))
