@@ -7,4 +7,4 @@ set -u
 N=${1:-2}
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p /tmp/shim && /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -shared -Wl,-soname,librccl.so.1 -o /tmp/shim/librccl.so.1 $R/tests/rccl_shim/rccl_shim.cpp -lrt 2>/dev/null
-LD_PRELOAD=/tmp/shim/librccl.so.1 timeout -k 10 400 python $R/bench.py --gpus $N --rehearse-backend gloo --rows 8000000 --steps 100 --warmup 10 --no-cpu-baseline --watchdog-s 300
+LD_PRELOAD=/tmp/shim/librccl.so.1 timeout -k 10 400 python $R/bench.py --gpus $N --rehearse-backend gloo --rows ${ROWS:-8000000} --steps 100 --warmup 10 --no-cpu-baseline --watchdog-s 300
