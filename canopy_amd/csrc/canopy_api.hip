@@ -517,7 +517,7 @@ canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, int32_t ker
         if (st != CANOPY_OK) return st;
         if (m->bs_state == 1) return CANOPY_OK;
         if (kernel == CANOPY_KERNEL_BAND_STREAM) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a band stream");
-        if (m->n_events > ws_max_events()) return CANOPY_OK; // AUTO: quantify falls back to ROWS
+        if (m->n_events > ws_max_events() || m->n_events <= 2048) return CANOPY_OK; // AUTO: quantify falls back to ROWS / ROWS_LDS
         // AUTO: the wave-slab stream instead
     } else if (variant != CANOPY_KERNEL_WAVE_STREAM) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "unknown kernel variant");
     canopy_status st = build_ws(ctx, m);

@@ -49,7 +49,10 @@ canopy_status fail(canopy_ctx* ctx, canopy_status st, const std::string& msg) {
 int auto_variant(const canopy_model* m) {
     // measured on MI355X (avg 6 nnz/row, 1e8 rows): the LDS-table row kernel wins up to E = 2048 (two
     // workgroups per CU still fit); beyond that the table costs occupancy and the wave-slab stream wins
-    if (m->n_events <= 2048) return CANOPY_KERNEL_ROWS_LDS;
+    // (round 3: at scale the band stream is ahead even there -- 1e8 rows, s_i written, E = 1e3 avg 4 / E = 2048 avg 6: ROWS_LDS 0.76 /
+    // 0.99 ms, BAND_STREAM 0.66 / 0.83, benchmarks/bs_small_e.py -- but it works in rounds of one 16384-row slab per CU (~40 us
+    // each): below ~2e7 rows the two are level and ROWS_LDS has no floor)
+    if (m->n_events <= 2048) return m->n_rows >= (int64_t)20000000 ? CANOPY_KERNEL_BAND_STREAM : CANOPY_KERNEL_ROWS_LDS;
     // round 2, E = 1e5, every row kept: ROWS 64 us / 113 us at 2e6 / 4e6 rows, WAVE_STREAM 72 / 75 (a ~50 us floor: few
     // wave-slabs, one wave each): the stream kernel from 2.5e6 rows
     // round 3: the band stream (workgroup-wide slabs) where its 17-bit columns reach: 0.93 against 1.19 ms per pass with s_i
@@ -327,7 +330,8 @@ canopy_status ensure_layouts(canopy_ctx* ctx, const canopy_model* m, const canop
         if (m->bs_state != 1) {
             if (params->kernel == CANOPY_KERNEL_BAND_STREAM)
                 return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a band stream");
-            pl.variant = m->n_events <= ws_max_events() ? CANOPY_KERNEL_WAVE_STREAM : CANOPY_KERNEL_ROWS; // AUTO
+            pl.variant = m->n_events <= 2048 ? CANOPY_KERNEL_ROWS_LDS // AUTO: what it ran before the band stream existed
+                                             : (m->n_events <= ws_max_events() ? CANOPY_KERNEL_WAVE_STREAM : CANOPY_KERNEL_ROWS);
         }
     }
     if (pl.variant == CANOPY_KERNEL_WAVE_STREAM) {
