@@ -336,16 +336,25 @@ __global__ __launch_bounds__(kBsThreads) __attribute__((amdgpu_waves_per_eu(kBsW
                 rem = __builtin_amdgcn_readfirstlane(ss_used[s]);                                                        \
             }                                                                                                            \
             if (s >= s_end) break;                                                                                       \
-            /* (all four gathers and the stream load first: taking turns -- one gather, one add -- was measured slower,     \
-               0.879 against 0.795 ms for the sum-only pass at config 3) */                                               \
-            VB[0] = logp[EB.x >> kBsRowBits]; VB[1] = logp[EB.y >> kBsRowBits];                                          \
-            VB[2] = logp[EB.z >> kBsRowBits]; VB[3] = logp[EB.w >> kBsRowBits];                                          \
-            BS_NEXT(EC)                                                                                                  \
+            /* The next superstep's gathers go out WHILE a band's adds drain (behind the adds, in front of the wait and the  \
+               barrier): the vector-memory issue time then overlaps the LDS latency instead of delaying the adds: 0.87 against \
+               0.90 ms with s_i written, same box. (All four gathers and the load in front of the adds: that 0.90; one gather, \
+               one add in turn: 0.88 sum-only against 0.80.) */                                                            \
             const uint32_t r4[4] = {EA.x & kBsRowMask, EA.y & kBsRowMask, EA.z & kBsRowMask, EA.w & kBsRowMask};         \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
-                __hip_atomic_fetch_add(&sums[r4[j]], VA[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);             \
-                if ((j + 1) % kBsGroupsPerBand == 0) bs_barrier(); /* the band is complete: its rows may appear again */ \
-            }                                                                                                            \
+            const uint32_t cB[4] = {EB.x >> kBsRowBits, EB.y >> kBsRowBits, EB.z >> kBsRowBits, EB.w >> kBsRowBits};     \
+            __hip_atomic_fetch_add(&sums[r4[0]], VA[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                 \
+            __hip_atomic_fetch_add(&sums[r4[1]], VA[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            VB[0] = logp[cB[0]]; VB[1] = logp[cB[1]]; /* issued while the band's adds drain */                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            bs_barrier();                                                                                                \
+            __hip_atomic_fetch_add(&sums[r4[2]], VA[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                 \
+            __hip_atomic_fetch_add(&sums[r4[3]], VA[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            VB[2] = logp[cB[2]]; VB[3] = logp[cB[3]];                                                                    \
+            BS_NEXT(EC)                                                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            bs_barrier();                                                                                                \
             --rem;                                                                                                       \
         }
         for (;;) {
