@@ -325,6 +325,28 @@ __global__ __launch_bounds__(kBsThreads) __attribute__((amdgpu_waves_per_eu(kBsW
         int rem = __builtin_amdgcn_readfirstlane(ss_used[s]);
         // EA / VA: the superstep whose adds happen now (its gathers went out one step ago); EB: loaded, its gathers go out now
         // into VB; EC: the stream load of the superstep after that
+#ifndef BS_ORDER
+#define BS_ORDER 1 // (0 / 1 / 2 / 3 at config 3 with s_i written, one box: 0.877 / 0.833 / 0.858 / 0.909 ms)
+#endif
+#define BS_ADD(V, J) __hip_atomic_fetch_add(&sums[r4[J]], V[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#define BS_SB __builtin_amdgcn_sched_barrier(0);
+#if BS_ORDER == 0
+#define BS_ORDER_BODY(EA, VA, EB, VB, EC) \
+            BS_ADD(VA, 0) BS_ADD(VA, 1) BS_SB VB[0] = logp[cB[0]]; VB[1] = logp[cB[1]]; BS_SB bs_barrier(); \
+            BS_ADD(VA, 2) BS_ADD(VA, 3) BS_SB VB[2] = logp[cB[2]]; VB[3] = logp[cB[3]]; BS_NEXT(EC) BS_SB bs_barrier();
+#elif BS_ORDER == 1 /* the stream load in the first drain */
+#define BS_ORDER_BODY(EA, VA, EB, VB, EC) \
+            BS_ADD(VA, 0) BS_ADD(VA, 1) BS_SB VB[0] = logp[cB[0]]; VB[1] = logp[cB[1]]; BS_NEXT(EC) BS_SB bs_barrier(); \
+            BS_ADD(VA, 2) BS_ADD(VA, 3) BS_SB VB[2] = logp[cB[2]]; VB[3] = logp[cB[3]]; BS_SB bs_barrier();
+#elif BS_ORDER == 2 /* add, gather, add, gather */
+#define BS_ORDER_BODY(EA, VA, EB, VB, EC) \
+            BS_ADD(VA, 0) BS_SB VB[0] = logp[cB[0]]; BS_SB BS_ADD(VA, 1) BS_SB VB[1] = logp[cB[1]]; BS_SB bs_barrier(); \
+            BS_ADD(VA, 2) BS_SB VB[2] = logp[cB[2]]; BS_SB BS_ADD(VA, 3) BS_SB VB[3] = logp[cB[3]]; BS_NEXT(EC) BS_SB bs_barrier();
+#elif BS_ORDER == 3 /* all four gathers and the load in the FIRST drain */
+#define BS_ORDER_BODY(EA, VA, EB, VB, EC) \
+            BS_ADD(VA, 0) BS_ADD(VA, 1) BS_SB VB[0] = logp[cB[0]]; VB[1] = logp[cB[1]]; VB[2] = logp[cB[2]]; VB[3] = logp[cB[3]]; BS_NEXT(EC) BS_SB bs_barrier(); \
+            BS_ADD(VA, 2) BS_ADD(VA, 3) BS_SB bs_barrier();
+#endif
 #define BS_STEP(EA, VA, EB, VB, EC)                                                                                      \
         {                                                                                                                \
             while (rem == 0) { /* slab finished (or without entries): every wave folds ITS 1024 rows, then the next slab */ \
@@ -342,19 +364,7 @@ __global__ __launch_bounds__(kBsThreads) __attribute__((amdgpu_waves_per_eu(kBsW
                one add in turn: 0.88 sum-only against 0.80.) */                                                            \
             const uint32_t r4[4] = {EA.x & kBsRowMask, EA.y & kBsRowMask, EA.z & kBsRowMask, EA.w & kBsRowMask};         \
             const uint32_t cB[4] = {EB.x >> kBsRowBits, EB.y >> kBsRowBits, EB.z >> kBsRowBits, EB.w >> kBsRowBits};     \
-            __hip_atomic_fetch_add(&sums[r4[0]], VA[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                 \
-            __hip_atomic_fetch_add(&sums[r4[1]], VA[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                           \
-            VB[0] = logp[cB[0]]; VB[1] = logp[cB[1]]; /* issued while the band's adds drain */                            \
-            __builtin_amdgcn_sched_barrier(0);                                                                           \
-            bs_barrier();                                                                                                \
-            __hip_atomic_fetch_add(&sums[r4[2]], VA[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                 \
-            __hip_atomic_fetch_add(&sums[r4[3]], VA[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                           \
-            VB[2] = logp[cB[2]]; VB[3] = logp[cB[3]];                                                                    \
-            BS_NEXT(EC)                                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                           \
-            bs_barrier();                                                                                                \
+            BS_ORDER_BODY(EA, VA, EB, VB, EC)                                                                            \
             --rem;                                                                                                       \
         }
         for (;;) {
@@ -363,6 +373,9 @@ __global__ __launch_bounds__(kBsThreads) __attribute__((amdgpu_waves_per_eu(kBsW
             BS_STEP(e2, v2, e0, v0, e1)
         }
 #undef BS_STEP
+#undef BS_ORDER_BODY
+#undef BS_ADD
+#undef BS_SB
     }
 #undef BS_NEXT
     if (n_pend > 0) fold_kept_row(acc.rare, acc.l1p, acc.n_certain, lane < n_pend ? pend[lane] : 0.0, lane < n_pend); // (wave-uniform)
