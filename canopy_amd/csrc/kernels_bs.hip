@@ -238,7 +238,9 @@ struct BsScalars {
 // the gathers already in flight and the loop's next wait stays a vmcnt(N) (behind a call the compiler waits for everything,
 // i.e. for the stores to be acknowledged -- with all 16 waves of the CU in the epilogue at once nothing hides that). The kept
 // s_i go to a per-wave pending list and are folded (exp, log1p, compensated sums) 64 at a time: at the default cut-off a
-// wave keeps ~9 of its 1024 rows per slab, a batch per slab would run 55 of 64 lanes empty.
+// wave keeps ~9 of its 1024 rows per slab, a batch per slab would run 55 of 64 lanes empty. (A lane taking PAIRS of rows --
+// 16-byte LDS reads and 16-byte stores of s_i, half the instructions -- measured no better: 0.885 against 0.881 ms with s_i
+// written; the row output costs its 0.8 GB of writes, not its store instructions.)
 template <bool ROWS, bool MASK>
 __device__ __forceinline__ void bs_epilogue(double* sums, double* pend, int& n_pend, int64_t s, int wave, int lane, Acc& acc, const BsScalars& sc,
                                             const int64_t* __restrict__ row_ptr, double* __restrict__ row_logp_out,
