@@ -329,7 +329,9 @@ __global__ __launch_bounds__(kBsThreads) __attribute__((amdgpu_waves_per_eu(kBsW
         // EA / VA: the superstep whose adds happen now (its gathers went out one step ago); EB: loaded, its gathers go out now
         // into VB; EC: the stream load of the superstep after that
 #ifndef BS_ORDER
-#define BS_ORDER 1 // (0 / 1 / 2 / 3 at config 3 with s_i written, one box: 0.877 / 0.833 / 0.858 / 0.909 ms)
+#define BS_ORDER 1 // (0 / 1 / 2 / 3 at config 3 with s_i written, one box: 0.877 / 0.833 / 0.858 / 0.909 ms; also measured: the
+                   // load in front of the adds 0.860, the load in front of the first drain's gathers 0.885, three gathers + the load in the
+                   // first drain 0.880 -- against 0.843 for order 1 on that box)
 #endif
 #define BS_ADD(V, J) __hip_atomic_fetch_add(&sums[r4[J]], V[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #define BS_SB __builtin_amdgcn_sched_barrier(0);
