@@ -335,7 +335,11 @@ __global__ __launch_bounds__(kBsThreads) __attribute__((amdgpu_waves_per_eu(kBsW
 #endif
 #define BS_ADD(V, J) __hip_atomic_fetch_add(&sums[r4[J]], V[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #define BS_SB __builtin_amdgcn_sched_barrier(0);
-#if BS_ORDER == 0
+#if BS_GPB == 1 /* (geometry experiment: a barrier behind every add) */
+#define BS_ORDER_BODY(EA, VA, EB, VB, EC) \
+            BS_ADD(VA, 0) BS_SB VB[0] = logp[cB[0]]; BS_NEXT(EC) BS_SB bs_barrier(); BS_ADD(VA, 1) BS_SB VB[1] = logp[cB[1]]; BS_SB bs_barrier(); \
+            BS_ADD(VA, 2) BS_SB VB[2] = logp[cB[2]]; BS_SB bs_barrier(); BS_ADD(VA, 3) BS_SB VB[3] = logp[cB[3]]; BS_SB bs_barrier();
+#elif BS_ORDER == 0
 #define BS_ORDER_BODY(EA, VA, EB, VB, EC) \
             BS_ADD(VA, 0) BS_ADD(VA, 1) BS_SB VB[0] = logp[cB[0]]; VB[1] = logp[cB[1]]; BS_SB bs_barrier(); \
             BS_ADD(VA, 2) BS_ADD(VA, 3) BS_SB VB[2] = logp[cB[2]]; VB[3] = logp[cB[3]]; BS_NEXT(EC) BS_SB bs_barrier();
