@@ -291,3 +291,29 @@ def test_random_coherent_trees_against_truth_tables(canopy_lib, seed):
         assert np.all(np.diff(col[row_ptr[i]:row_ptr[i + 1]]) > 0)
     lo = ft.cut_sets(limit_order=2)
     assert csr_rows(*lo) == [s for s in want_sets if len(s) <= 2]
+
+
+@pytest.mark.gpu
+def test_c_example_ticket_sequence(canopy_lib, gpu_ctx, tmp_path):
+    """examples/ticket_sequence.c: a C99 consumer of canopy.h built with gcc -- a new probability vector per pass, results by
+    ticket with up to three passes in flight -- against the same sequence through the Python binding, one pass at a time."""
+    import json
+    import subprocess
+    import numpy as np
+    import canopy_amd
+    exe = tmp_path / "ticket_sequence"
+    lib_dir = os.path.join(ROOT, "canopy_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-O2", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "ticket_sequence.c"), "-L", lib_dir, "-lcanopy", "-Wl,-rpath," + lib_dir, "-lm",
+                    "-o", str(exe)], check=True)
+    rows, events, n = 1_500_000, 30_000, 9
+    out = subprocess.run([str(exe), str(rows), str(events), str(n)], check=True, capture_output=True, text=True).stdout
+    got = json.loads(out)["results"]
+    assert len(got) == n
+    model = gpu_ctx.synthetic(20250704, rows, events, 6)
+    base = canopy_amd.synthetic_probabilities(20250704, events)
+    for k in range(n):
+        model.set_probabilities(np.minimum(1.0, base * (0.5 + k / (n - 1))))
+        want = gpu_ctx.quantify(model)
+        assert (got[k]["n_kept"], got[k]["rare_event"], got[k]["mcub"]) == (want.n_kept, want.rare_event, want.mcub), k
+    model.close()
