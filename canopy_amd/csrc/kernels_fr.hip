@@ -516,7 +516,8 @@ struct Q8Chunk { // one lane's share of a chunk in flight: 32-bit form x y z w =
 };
 
 template <bool P24>
-__device__ __forceinline__ Q8Chunk q8_load_chunk(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ cbase, int64_t c, int lane) {
+__device__ __forceinline__ Q8Chunk q8_load_chunk(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ cbase, int64_t c, int lane,
+                                                 uint32_t zero = 0u, bool zero_given = false) {
     Q8Chunk r;
     if (P24) {
         // (wave-uniform chunk pointer + a 32-bit lane offset: the load takes the pointer from scalar registers; as
@@ -530,9 +531,13 @@ __device__ __forceinline__ Q8Chunk q8_load_chunk(const uint32_t* __restrict__ st
         // add. (That is what held the first 24-bit and 16-bit attempts at the 32-bit stream's time.)
         // (address space 1 = global: a generic pointer would become flat_load, which counts in lgkmcnt as well)
         // (scalar base + an opaque zero in a vector register: no address arithmetic on the vector ALU)
-        uint32_t zero = 0u;
-        asm volatile("" : "+v"(zero));
-        r.w = fr_uniform_ptr(cbase + c)[zero];
+        // (a BYTE offset on a char pointer: as an element index the compiler scaled it with a 64-bit vector add into a register
+        // pair it had just used as the destination of a chunk load in flight -- and waited for that load: `vmcnt(0)` every pass)
+        // (`zero`: the caller's opaque zero, made ONCE per kernel and kept in a register of its own -- made here, per load, it
+        // landed in a register that was the destination of a chunk load still in flight: the same wait)
+        if (!zero_given) asm volatile("" : "+v"(zero));
+        const char __attribute__((address_space(1))) * bp = reinterpret_cast<const char __attribute__((address_space(1))) *>(fr_uniform_ptr(cbase + c));
+        r.w = *reinterpret_cast<const uint32_t __attribute__((address_space(1))) *>(bp + zero);
     } else {
         const uint32_t __attribute__((address_space(1))) * p = fr_uniform_ptr(stream + c * (int64_t)(kWave * 4)) + (uint32_t)lane * 4u;
         r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
@@ -700,6 +705,8 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8o(const uint32_t* __
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    uint32_t zero_v = 0u; // an opaque zero byte offset in a vector register (q8_load_chunk)
+    asm volatile("" : "+v"(zero_v));
     const int64_t G = (int64_t)gridDim.x;
     // A CONTIGUOUS block of slabs per workgroup (the first n_slabs % G workgroups take one more), not slabs blockIdx, blockIdx + G,
     // ...: 1 % faster at config 3 (0.3276 against 0.3313 ms per step, three alternated runs each on one box; giving every XCD a
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8o(const uint32_t* __
         const int64_t f1 = __builtin_amdgcn_readfirstlane(exc[(SLAB)]) != 0 ? f0 : fr_uload(fr_off + (SLAB) + 1); \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                             \
             const int64_t c = f0 + wave + (int64_t)u * kQ8Waves;                                    \
-            q[u] = q8_load_chunk<true>(stream, cbase, c < f1 ? c : total_chunks, lane);             \
+            q[u] = q8_load_chunk<true>(stream, cbase, c < f1 ? c : total_chunks, lane, zero_v, true); \
         }                                                                                           \
     }
     FRO_FIRST_CHUNKS(s_begin)
@@ -792,9 +799,10 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8o(const uint32_t* __
 #define Q8O_HALF(QC, QN, CB)                                                                                           \
             {                                                                                                          \
                 _Pragma("unroll") for (int u = 0; u < U; ++u) { /* next step's chunks first */                          \
-                    const int64_t c = (CB) + (int64_t)(U + u) * kQ8Waves;                                              \
-                    QN[u] = q8_load_chunk<true>(stream, cbase, c < c1 ? c : total_chunks, lane);                       \
-                }                                                                                                      \
+                    const int rc = (CB) + (U + u) * kQ8Waves; /* relative to the slab's first chunk: 32-bit SCALAR compares */ \
+                    QN[u] = q8_load_chunk<true>(stream, cbase, rc < n_c ? c0 + rc : total_chunks, lane, zero_v, true); \
+                } /* (pinned in front of the step's LDS work with a scheduling barrier: 0.330 against 0.315 ms per step -- the        \
+                     compiler's own placement of these requests is the better one) */                                        \
                 _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                        \
                     uint32_t col[4], row[4];                                                                           \
                     q8_decode<true>(QC[u], col, row);                                                                  \
@@ -808,13 +816,17 @@ __global__ __launch_bounds__(kQ8Threads) void k_fr_filter_q8o(const uint32_t* __
             {
                 Q8Chunk q2[U];
                 bool in_q = true; // which set holds the chunks requested last (after the loop: the no-op chunks past the end)
-                for (int64_t cb = c0 + wave; cb < c1;) {
+                // (a 64-bit `cb < c1` is a VECTOR compare whose operand the compiler moved into registers it had just used as the
+                // destination of a chunk load still in flight -- and waited for that load first: `s_waitcnt vmcnt(0)` at the top
+                // of this loop, every pass)
+                const int n_c = (int)(c1 - c0);
+                for (int cb = wave; cb < n_c;) {
                     Q8O_HALF(q, q2, cb)
-                    cb += (int64_t)U * kQ8Waves;
+                    cb += U * kQ8Waves;
                     in_q = false;
-                    if (cb >= c1) break;
+                    if (cb >= n_c) break;
                     Q8O_HALF(q2, q, cb)
-                    cb += (int64_t)U * kQ8Waves;
+                    cb += U * kQ8Waves;
                     in_q = true;
                 }
                 (void)in_q;
