@@ -1167,9 +1167,19 @@ __device__ __forceinline__ double refine_row_sum(const RowKernelArgs& a, int64_t
         int32_t c[8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { c[u] = (k0 + u < len) ? q0.c[u] : 0; c[4 + u] = (k0 + 4 + u < len) ? q1.c[u] : 0; }
+        // The gathers of a trip go out TOGETHER: four unconditional ones (positions past the row gather entry 0: a cached line),
+        // the other four under ONE wave-uniform test. One test per gather put every gather into a basic block of its own with a
+        // `s_waitcnt vmcnt(0)` in front (the ISA showed): two or three memory round trips per trip instead of one.
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (u < n_here) v[u] = a.logp[c[u]];
+        for (int u = 0; u < 4; ++u) v[u] = a.logp[c[u]];
+        if (n_here > 4) {
+#pragma unroll
+            for (int u = 4; u < 8; ++u) v[u] = a.logp[c[u]];
+        } else {
+#pragma unroll
+            for (int u = 4; u < 8; ++u) v[u] = 0.0;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (u < n_here && k0 + u < len) s = s + v[u]; // plain adds, CSR order
     }
