@@ -66,8 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--comm-mode", choices=("chained", "unordered", "own-stream"), default="chained",
                     help="how consecutive collectives of the communicator are ordered on the device (canopy_comm_set_mode)")
     ap.add_argument("--lanes", type=int, default=0,
-                    help="lanes consecutive passes rotate through (2..4); 0 = what measured best: 4 for the whole model on one GPU "
-                         "(0.330 against 0.336 ms per step), 3 for the short passes of a shard (45.9 against 49.0 us at the 8-way size)")
+                    help="lanes consecutive passes rotate through (2..4); 0 = what measured best: 4 (0.318 against 0.323 ms per step for the "
+                         "whole model; 42.7 against 46.3 us at the 8-way shard size)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="A/B: passes strictly one after the other on one stream (canopy_ctx_set_pipeline(0))")
     ap.add_argument("--no-fetch", action="store_true", help="A/B: the timed steps are enqueued without fetching their records")
@@ -380,10 +380,10 @@ def main():
     def rec_tuple(parts):
         return tuple((q.rare_hi, q.rare_lo, q.log1p_hi, q.log1p_lo, q.n_kept, q.n_certain, q.max_logp, q.argmax_row) for q in parts)
 
-    depth = {"n": 3}  # steps in flight: three lanes when pipelined, ONE otherwise (un-pipelined passes share a lane,
+    depth = {"n": 4}  # steps in flight: as many as lanes when pipelined, ONE otherwise (un-pipelined passes share a lane,
     #                    which keeps the record of its last ticketed pass only: fetch before the next enqueue)
 
-    lanes = args.lanes if args.lanes >= 2 else (3 if (world > 1 or args.force_dist or args.shard_of > 1) else 4)
+    lanes = args.lanes if args.lanes >= 2 else 4
 
     def set_pipeline(on):
         ctx.set_pipeline(lanes if on else 0)

@@ -238,7 +238,7 @@ canopy_status canopy_ctx_set_pipeline(canopy_ctx* ctx, int32_t enable) try {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // nothing in flight while the rotation changes
     for (auto& S : ctx->sets) { S.pending_lo = 0; S.pending = false; }
     ctx->pipeline_on = enable != 0;
-    ctx->n_lanes = enable >= 2 ? (enable > canopy_ctx::kLanes ? canopy_ctx::kLanes : enable) : 3;
+    ctx->n_lanes = enable >= 2 ? (enable > canopy_ctx::kLanes ? canopy_ctx::kLanes : enable) : 4;
     if (ctx->pipe_next >= ctx->n_lanes) ctx->pipe_next = 0;
     return CANOPY_OK;
 } CANOPY_CATCH_ALL

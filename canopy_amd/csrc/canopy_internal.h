@@ -78,7 +78,7 @@ struct canopy_ctx {
     // when already satisfied): the host blocks before it reuses a lane until that lane's previous pass has finished.
     // Lane 0 is the context's own stream; passes with per-row outputs and the other kernel variants run there, behind
     // everything the other lanes still hold.
-    static constexpr int kLanes = 4; // at most; n_lanes of them rotate (canopy_ctx_set_pipeline: default 3)
+    static constexpr int kLanes = 4; // at most; n_lanes of them rotate (canopy_ctx_set_pipeline: default 4)
     struct PassScratch {
         hipStream_t stream = nullptr;       // lane 0: the context's stream
         double* d_block_partials = nullptr; // [block_partials_cap][8]
@@ -116,7 +116,7 @@ struct canopy_ctx {
     } ring[kTicketRing];
     double* h_ring = nullptr;     // pinned [kTicketRing][16]: the shard record [0..8), the filter's candidate total as u64 at [8]
     bool pipeline_on = true;      // canopy_ctx_set_pipeline
-    int n_lanes = 3;              // lanes consecutive pipelined passes rotate through (2 .. kLanes)
+    int n_lanes = 4;              // lanes consecutive pipelined passes rotate through (2 .. kLanes; round 3, late: four -- 42.7 against 46.3 us per step at the 8-way shard size once the filter had got faster, 0.318 against 0.323 ms for the whole model)
     int pipe_next = 0;            // lane of the next pipelined pass
     int last_set = 0;             // lane of the last pass (its record and candidate count are fetched from there)
     double* d_partial = nullptr;        // the shard record, 8 doubles

@@ -101,19 +101,19 @@ CANOPY_API canopy_status canopy_ctx_synchronize(canopy_ctx* ctx);
 /*
  * Pipelining of consecutive passes (default: on). A sum-only FILTER_REFINE / FIXED_SUM pass is a row kernel that streams the whole model (HBM-bound, every
  * CU busy) followed by a latency-bound tail (exact pass over the listed rows, final reduce, and with a communicator
- * the all-reduce). With pipelining on, consecutive such passes rotate through three internal lanes -- a stream, scratch,
+ * the all-reduce). With pipelining on, consecutive such passes rotate through four internal lanes (canopy_ctx_set_pipeline's default) -- a stream, scratch,
  * record and all-reduce slot buffer each -- and the device overlaps them: the next pass's row kernel takes the CUs as
  * this pass's row kernel leaves them, while this pass's tail runs beside it. A sequence of passes (uncertainty trials,
  * repeated quantification after canopy_model_set_probabilities, the benchmark's steps) is then paced by the row kernel
  * alone. canopy_quantify_fetch / canopy_comm_fetch deliver the LAST enqueued pass and wait for every lane;
  * canopy_quantify_enqueue hands out a TICKET per pass instead, and canopy_ticket_fetch / canopy_comm_ticket_fetch wait
  * for that pass's lane only -- a caller that needs every pass's result (uncertainty trials, a new probability vector
- * per pass) keeps up to three passes in flight and still runs at the pipelined rate. canopy_model_set_probabilities
+ * per pass) keeps up to four passes in flight and still runs at the pipelined rate. canopy_model_set_probabilities
  * does not drain the lanes either (it writes the next of the model's four probability sets). The host
- * may block in canopy_quantify_async until the pass three back has finished; passes that ask for per-row outputs,
+ * may block in canopy_quantify_async until the pass four back has finished; passes that ask for per-row outputs,
  * keep masks or importance, all other kernel variants, and contexts with a caller-owned gather buffer
  * (canopy_ctx_set_gather_buffer) run un-pipelined on the context's stream behind whatever is still in flight.
- * enable: 0 = off (one pass at a time on the context's stream), 1 = on with the default of three lanes, 2 .. 4 = on with that
+ * enable: 0 = off (one pass at a time on the context's stream), 1 = on with the default of four lanes, 2 .. 4 = on with that
  * many lanes (a fourth lane buys slack for a slow cross-GPU collective in the tail of a short shard pass). The call
  * waits for everything in flight.
  */
