@@ -241,6 +241,8 @@ def moved_bytes(variant, info, listed_rows):
                        written and read back;
       every other pass the canonical CSR (algorithmic bytes).
     """
+    if variant == 5 and getattr(info, "stream_bytes_rows", 0):  # the row stream: the exact pass reads a third line per listed row (the permutation)
+        return info.stream_bytes_rows + (listed_rows or 0) * (3 * 128 + 4)
     if variant == 5 and info.stream_bytes:
         return info.stream_bytes + (listed_rows or 0) * (2 * 128 + 4)
     if variant == 6 and info.stream_bytes_wide:  # the fixed-point pass streams the 32-bit form of the slab stream

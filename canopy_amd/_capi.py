@@ -48,7 +48,7 @@ class ModelInfo(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("nnz", C.c_int64), ("row_offset", C.c_int64),
                 ("n_events", C.c_int32), ("max_row_len", C.c_int32),
                 ("device_bytes", C.c_int64), ("stream_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64),
-                ("stream_bytes_wide", C.c_int64), ("stream_bytes_exact", C.c_int64)]
+                ("stream_bytes_wide", C.c_int64), ("stream_bytes_exact", C.c_int64), ("stream_bytes_rows", C.c_int64)]
 
 
 class QuantParams(C.Structure):

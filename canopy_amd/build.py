@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcanopy.so")
 
-SOURCES = ["canopy_api.hip", "quantify_pass.hip", "host_pool.cpp", "kernels_rows.hip", "kernels_build.hip", "kernels_ws.hip", "kernels_bs.hip", "kernels_vs.hip", "kernels_mc.hip", "kernels_fr.hip",
+SOURCES = ["canopy_api.hip", "quantify_pass.hip", "host_pool.cpp", "kernels_rows.hip", "kernels_build.hip", "kernels_ws.hip", "kernels_bs.hip", "kernels_ls.hip", "kernels_vs.hip", "kernels_mc.hip", "kernels_fr.hip",
            "kernels_batch.hip", "comm_rccl.hip", "mef_lowering.cpp"]
 HEADERS = ["canopy_device.h", "canopy_internal.h", "canopy_guard.h"]
 

@@ -62,6 +62,8 @@ void free_model_buffers(canopy_model* m) {
     if (m->fr24.base) (void)hipFree(m->fr24.base);
     if (m->fr24.exc) (void)hipFree(m->fr24.exc);
     m->fr24 = FrP24Owned();
+    ls_free(&m->ls);
+    m->ls_state = 0;
     if (m->d_off16) (void)hipFree(m->d_off16);
     m->d_off16 = nullptr;
     m->d_vs_stream = nullptr; m->d_vs_off = nullptr; m->d_vs_slab_row = nullptr; m->vs_state = 0;
@@ -388,6 +390,7 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
         info->stream_bytes = m->vs_total_chunks * 1024 + (m->n_slabs + 1) * 16 + (m->n_rows + 1) * 8 + (int64_t)m->n_events * 8;
     else if (m->ws_state == 1)
         info->stream_bytes = m->ws_total_chunks * 1024 + (m->n_ws + 1) * 8 + (int64_t)m->n_events * 8;
+    info->stream_bytes_rows = m->ls_state == 1 ? m->ls.stream_bytes + (int64_t)m->n_events * 8 : 0;
     info->stream_bytes_exact = 0;
     if (m->bs_state == 1)
         info->stream_bytes_exact = m->bs_used_ss * bs_ss_bytes() + m->n_bs_slabs * 12 + (int64_t)m->n_events * 8;

@@ -231,6 +231,16 @@ struct canopy_dag {
     std::vector<int32_t> reg_level_gates; // gates per level (host copy: the launch derives the per-lane schedule from it)
 };
 
+struct LsOwned { // the quantised filter's row stream (kernels_ls.hip), owned by the model
+    uint32_t* ent = nullptr;   // [n_lines][64] the lanes' bit streams, a range (step, wave) after the other
+    uint32_t* bm = nullptr;    // [n_units] item ends of every unit of 32 entry rows
+    void* desc = nullptr;      // [n_steps * 16 + 1] ranges: first line, entry rows, first unit
+    uint16_t* perm16 = nullptr;// [n_slabs * 8192] list position -> local row id
+    int64_t n_lines = 0, n_units = 0, n_steps = 0, n_slabs = 0;
+    int bits = 0;
+    int64_t stream_bytes = 0, device_bytes = 0;
+};
+
 struct FrP24Owned { // device buffers of the 24-bit stream form, owned by the model
     uint32_t* stream = nullptr;
     uint32_t* base = nullptr;
@@ -280,6 +290,8 @@ struct canopy_model {
     mutable FrP24Owned fr24; // 24-bit form of the same chunks (quantised filter), or nulls
     mutable uint16_t* d_off16 = nullptr; // [n_rows + 1] row start minus the start of the row's 8192-row block (null: some block holds > 65535 entries)
     mutable int fr_state = 0;
+    mutable LsOwned ls;       // the row stream of the quantised filter (E <= 112 K), built with the slab stream
+    mutable int ls_state = 0; // 0 not built, 1 ready, -1 the model has none
 };
 
 namespace canopy {
@@ -416,16 +428,31 @@ struct FrP24 {
 bool fr_p24_applies(int32_t n_events);
 hipError_t fr_build_pack24(const uint32_t* d_stream32, const int64_t* d_fr_off, int64_t n_slabs, int64_t total_chunks, int32_t n_events,
                            FrP24Owned* p, hipStream_t s);
+// the row stream of the quantised filter (kernels_ls.hip): lists of POSITIONS, translated by perm16 in the exact pass
+struct LsView {
+    const uint32_t* ent = nullptr;
+    const uint32_t* bm = nullptr;
+    const void* desc = nullptr;
+    const uint16_t* perm16 = nullptr;
+    int64_t n_steps = 0, n_slabs = 0;
+    int bits = 0;
+};
+bool ls_applies(int32_t n_events);
+void ls_free(LsOwned* L);
+hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events, LsOwned* out, bool* ok, hipStream_t s);
+hipError_t launch_ls_filter(const LsView& L, const uint8_t* q8, int32_t n_events, int threshold, uint16_t* cand_list, unsigned* cand_cnt,
+                            unsigned long long* cand_count, int n_cu, hipStream_t s);
 hipError_t launch_fr_q8_table(const double* logp, int32_t n_events, double log_cut, uint8_t* q8_buf, hipStream_t s);
 bool fr_q8_overlapped(const FrP24* p24, int32_t n_events, int32_t max_row_len);
 void fr_q8_overlapped_units(int* unit_rows, int* units_per_slab);
 hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool overlapped, int32_t max_row_len, const int64_t* fr_off,
                                int64_t total_chunks, const double* logp, uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs,
                                double log_cut, uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count,
-                               int n_cu, bool table_valid, hipStream_t s);
+                               int n_cu, bool table_valid, hipStream_t s, const LsView* ls = nullptr);
 // flagged: the lists come from launch_fx_sum (flag bits 15 / 14 per entry); records go to block_partials[part_offset + block]
 hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, const unsigned* cand_cnt, int slab_rows,
-                            int64_t n_slabs, uint64_t* keep_mask, int grid, bool flagged, int part_offset, hipStream_t s);
+                            int64_t n_slabs, uint64_t* keep_mask, int grid, bool flagged, int part_offset, hipStream_t s,
+                            const uint16_t* perm16 = nullptr);
 int fx_max_row_len();
 int fx_sum_grid(int n_cu, int32_t n_events, int64_t n_slabs);
 void fx_list_units(int32_t n_events, int* unit_rows, int* units_per_slab);

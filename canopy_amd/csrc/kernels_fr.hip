@@ -478,7 +478,11 @@ __global__ __launch_bounds__(FrCfg<SLAB_ROWS>::threads) void k_fr_filter(const u
 __global__ __launch_bounds__(256) void k_fr_q8_table(const double* __restrict__ logp, int32_t n_events, double inv_step,
                                                      uint8_t* __restrict__ q8) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_events) return;
+    if (j >= n_events) { // the row stream's two sentinel columns (kernels_ls.hip): a padding entry, a row past the model's end
+        if (j == n_events) q8[j] = 0;
+        else if (j == n_events + 1) q8[j] = 255;
+        return;
+    }
     const double neg = -logp[j]; // >= 0, +inf for p = 0
     // (1 - 2^-30): the bound must stay a lower bound although (a) the product may round up across an
     // integer and (b) the CSR-order fp64 sum s_i differs from the exact sum by up to len * 2^-53 relative
@@ -1189,11 +1193,13 @@ __device__ __forceinline__ double refine_row_sum(const RowKernelArgs& a, int64_t
 // FLAGGED (lists of the fixed-point pass k_fx_sum): bit 15 of an entry = "pass A left this row out: account for it
 // here if it is kept", bit 14 = "argmax contender: its exact s_i takes part in max / argmax"; the filters' lists carry
 // no flags and mean both. Records go to block_partials[part_offset + blockIdx.x].
-template <bool FLAGGED>
+// PERM (lists of the row stream, kernels_ls.hip): an entry is a POSITION of its slab, perm16 names the row; the rows of a lane
+// then do not ascend, so an argmax tie is settled here (lower row) and not by arrival.
+template <bool FLAGGED, bool PERM = false>
 __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArgs a, const uint16_t* __restrict__ cand_list,
                                                                    const unsigned* __restrict__ cand_cnt, int slab_rows,
                                                                    int64_t n_slabs, uint64_t* __restrict__ keep_mask,
-                                                                   int part_offset) {
+                                                                   int part_offset, const uint16_t* __restrict__ perm16 = nullptr) {
     __shared__ double s_red[kRefineWaves * kAccDoubles];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -1209,7 +1215,8 @@ __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArg
         const int64_t base = s * slab_rows;
         for (int j0 = (int)(u & 1) * kWave; j0 < n; j0 += 2 * kWave) {
             const bool on = j0 + lane < n;
-            const unsigned entry = on ? (unsigned)cand_list[base + j0 + lane] : 0u;
+            unsigned entry = on ? (unsigned)cand_list[base + j0 + lane] : 0u;
+            if (PERM) entry = on ? (unsigned)perm16[base + entry] : 0u;
             const bool account = !FLAGGED || (entry & 0x8000u) != 0, contend = !FLAGGED || (entry & 0x4000u) != 0;
             const int64_t r = base + (int64_t)(FLAGGED ? (entry & 0x3FFFu) : entry);
             int len = 0;
@@ -1221,7 +1228,10 @@ __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArg
             if (keep) {
                 if (account) acc.n_kept += 1.0;
                 // rows arrive in ascending order per lane, ties resolve to the lower row in acc_merge
-                if (contend && sv > acc.max_logp) { acc.max_logp = sv; acc.argmax = (double)(a.row_offset + r); }
+                if (contend && (sv > acc.max_logp || (PERM && sv == acc.max_logp && (double)(a.row_offset + r) < acc.argmax))) {
+                    acc.max_logp = sv;
+                    acc.argmax = (double)(a.row_offset + r);
+                }
                 if (account && keep_mask != nullptr)
                     atomicOr(reinterpret_cast<unsigned long long*>(&keep_mask[r >> 6]), 1ULL << (r & 63));
             }
@@ -1914,14 +1924,14 @@ hipError_t launch_fr_q8_table(const double* logp, int32_t n_events, double log_c
         return hipGetLastError();
     }
     const double inv_step = (double)kQ8Levels / mag;
-    hipLaunchKernelGGL(k_fr_q8_table, dim3(grid_for(n_events, 256)), dim3(256), 0, s, logp, n_events, inv_step, q8_buf);
+    hipLaunchKernelGGL(k_fr_q8_table, dim3(grid_for(n_events + 2, 256)), dim3(256), 0, s, logp, n_events, inv_step, q8_buf);
     return hipGetLastError();
 }
 
 hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool overlapped, int32_t max_row_len, const int64_t* fr_off,
                                int64_t total_chunks, const double* logp, uint8_t* q8_buf, int64_t n_rows, int32_t n_events, int64_t n_slabs,
                                double log_cut, uint16_t* cand_list, unsigned* cand_cnt, unsigned long long* cand_count,
-                               int n_cu, bool table_valid, hipStream_t s) {
+                               int n_cu, bool table_valid, hipStream_t s, const LsView* ls) {
     const double mag = -log_cut > 1.0 ? -log_cut : 1.0;
     const bool nib = fr_q8_nibble(n_events);
     const double inv_step = (double)(nib ? kQ4Levels : kQ8Levels) / mag;
@@ -1933,6 +1943,8 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
         e = launch_fr_q8_table(logp, n_events, log_cut, q8_buf, s);
         if (e != hipSuccess) return e;
     }
+    if (ls != nullptr && !nib) // the row stream (kernels_ls.hip): the same table and threshold, lists of positions
+        return launch_ls_filter(*ls, q8_buf, n_events, threshold, cand_list, cand_cnt, cand_count, n_cu, s);
     static const int u = CANOPY_TUNE_ENV("CANOPY_FR_QU") ? atoi(CANOPY_TUNE_ENV("CANOPY_FR_QU")) : 4; // tuning only (chunks in flight per wave)
     static const int fr_dbg = CANOPY_TUNE_ENV("CANOPY_FR_DEBUG") ? atoi(CANOPY_TUNE_ENV("CANOPY_FR_DEBUG")) : 0; // timing ablations only
     const int H = fr_parts_for(n_events);
@@ -2043,13 +2055,19 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
 }
 
 hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, const unsigned* cand_cnt, int slab_rows,
-                            int64_t n_slabs, uint64_t* keep_mask, int grid, bool flagged, int part_offset, hipStream_t s) {
+                            int64_t n_slabs, uint64_t* keep_mask, int grid, bool flagged, int part_offset, hipStream_t s,
+                            const uint16_t* perm16) {
+    if (perm16 != nullptr && !flagged) {
+        hipLaunchKernelGGL((k_fr_refine<false, true>), dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows,
+                           n_slabs, keep_mask, part_offset, perm16);
+        return hipGetLastError();
+    }
     if (flagged)
-        hipLaunchKernelGGL(k_fr_refine<true>, dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows,
-                           n_slabs, keep_mask, part_offset);
+        hipLaunchKernelGGL((k_fr_refine<true, false>), dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows,
+                           n_slabs, keep_mask, part_offset, (const uint16_t*)nullptr);
     else
-        hipLaunchKernelGGL(k_fr_refine<false>, dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows,
-                           n_slabs, keep_mask, part_offset);
+        hipLaunchKernelGGL((k_fr_refine<false, false>), dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows,
+                           n_slabs, keep_mask, part_offset, (const uint16_t*)nullptr);
     return hipGetLastError();
 }
 

@@ -113,6 +113,15 @@ canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m) {
             m->device_bytes -= (m->fr_total_chunks + 1) * 1024;
         }
     }
+    // the row stream of the quantised filter (kernels_ls.hip): what a sum-only pass at E <= 112 K reads instead of the chunks
+    // (optional: the pass runs on the chunks without it)
+    if (m->ls_state == 0) {
+        bool ls_ok = false;
+        e = ls_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, &m->ls, &ls_ok, ctx->stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); ls_ok = false; }
+        m->ls_state = ls_ok ? 1 : -1;
+        if (ls_ok) m->device_bytes += m->ls.device_bytes;
+    }
     m->fr_state = 1;
     return CANOPY_OK;
 }
@@ -520,6 +529,7 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
         if (pl.want_mask && pl.variant == CANOPY_KERNEL_FILTER_REFINE && !pl.filter_only) // the refine pass ORs the exact keep bits into a cleared mask
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_keep_mask, 0, mask_bytes, ctx->stream));
         bool q8_overlapped = false; // the quantised filter ran with the end step folded into the next iterations
+        bool use_ls = false;        // ... over the row stream: its lists hold positions
         if (pl.variant == CANOPY_KERNEL_FIXED_SUM) {
             // pass A writes records [0, grid_fx) and every word of the keep mask; the exact pass adds records [grid_fx, ..)
             HIP_TRY(ctx, launch_fx_sum(m->d_fr_stream, m->d_fr_off, m->fr_total_chunks, P->d_fx, m->d_row_ptr, m->n_rows, m->n_events,
@@ -530,9 +540,17 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
             FrP24 p24;
             p24.stream = m->fr24.stream; p24.base = m->fr24.base; p24.exc = m->fr24.exc;
             q8_overlapped = fr_q8_overlapped(&p24, m->n_events, m->max_row_len);
+            // the row stream when the model has one (its lists hold positions: the batch path, which reads the lists itself,
+            // stays on the chunks)
+            LsView lsv;
+            use_ls = m->ls_state == 1 && !pl.filter_only && fr_slab_rows(m->n_events) == 8192;
+            if (use_ls) {
+                lsv.ent = m->ls.ent; lsv.bm = m->ls.bm; lsv.desc = m->ls.desc; lsv.perm16 = m->ls.perm16;
+                lsv.n_steps = m->ls.n_steps; lsv.n_slabs = m->ls.n_slabs; lsv.bits = m->ls.bits;
+            }
             HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, &p24, q8_overlapped, m->max_row_len, m->d_fr_off, m->fr_total_chunks, P->d_logp, P->d_q8, m->n_rows,
                                              m->n_events, m->n_fr_slabs, a.log_cut, S.d_fr_list, S.d_fr_cnt, S.d_fr_count,
-                                             ctx->n_cu, !q8_in_graph, lane));
+                                             ctx->n_cu, !q8_in_graph, lane, use_ls ? &lsv : nullptr));
         } else {
             // delta covers the rounding difference between the unordered pass-A sum and the CSR-order sum
             const double cand_cut = a.log_cut - (1e-9 + 1e-11 * (double)m->max_row_len);
@@ -542,6 +560,7 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
         }
         int unit_rows = slab_rows, units_per_slab = 1; // list units the exact pass walks
         if (pl.variant == CANOPY_KERNEL_FIXED_SUM) fx_list_units(m->n_events, &unit_rows, &units_per_slab);
+        else if (use_ls) { unit_rows = 8192; units_per_slab = 1; }
         else if (q8_overlapped) fr_q8_overlapped_units(&unit_rows, &units_per_slab);
         if (pl.filter_only && pl.variant == CANOPY_KERNEL_FILTER_REFINE) {
             // the batch path lists, marks and compacts the candidates itself (kernels_batch.hip): nothing else to run
@@ -558,7 +577,7 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
         if ((int64_t)grid > g_need) grid = (int)g_need; // a small shard does not pay for 2048 workgroups' records
         HIP_TRY(ctx, launch_fr_refine(a, S.d_fr_list, S.d_fr_cnt, unit_rows, n_units,
                                       pl.want_mask ? ctx->d_keep_mask : nullptr, grid, pl.variant == CANOPY_KERNEL_FIXED_SUM, pl.grid_fx,
-                                      lane));
+                                      lane, use_ls ? m->ls.perm16 : nullptr));
         n_records = grid + pl.grid_fx;
     } else if (pl.variant == CANOPY_KERNEL_VALUE_SCATTER) {
         HIP_TRY(ctx, launch_vs_kernel(a, m->d_vs_stream, m->d_vs_off, m->d_vs_slab_row, m->vs_total_chunks, m->n_slabs,
