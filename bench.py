@@ -741,7 +741,7 @@ def main():
                 "algorithmic_bytes_per_launch": info.algorithmic_bytes,
                 "bytes_per_cut_set": moved / max(info.n_rows, 1),
                 "canonical_bytes_per_cut_set": info.algorithmic_bytes / max(info.n_rows, 1),
-                "stream_bytes_per_launch": info.stream_bytes,
+                "stream_bytes_per_launch": (getattr(info, "stream_bytes_rows", 0) if variant == 5 else 0) or info.stream_bytes,
                 "rows_to_exact_pass": listed,
                 "avg_kernel_ms": k_mean, "median_kernel_ms": k_med, "min_kernel_ms": k_min,
                 "avg_pass_ms": p_mean, "median_pass_ms": p_med, "min_pass_ms": p_min, "launches_timed": n_timed,

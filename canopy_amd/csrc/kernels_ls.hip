@@ -10,14 +10,15 @@
 //     stream at all;
 //   * a lane's columns are a bit stream of BITS = 17 (16 up to 65534 events) bits per entry; 32 entry rows = BITS dwords
 //     per lane = one UNIT of BITS 256-byte lines: 2.125 bytes per entry instead of 3.03;
-//   * sorted item i of a slab belongs to wave i % 16 (every wave gets every length class); the 8 items a wave has in each
+//   * the sorted items of a slab go to the 16 waves in a serpentine (every wave gets the same share of every length class:
+//     ls_item_of); the 8 items a wave has in each
 //     of the kLsStepSlabs consecutive slabs of a STEP are contiguous: a wave streams one RANGE per step, in units, one
 //     workgroup barrier per step;
 //   * per entry: one bit-field extract -> one ds_read_u8 of the 8-bit table in LDS -> a register add. No LDS atomics, no
 //     row sums in LDS. A bit mask per unit says where items end: there one ballot goes to LDS. After the step's barrier
 //     every wave turns the step's 512 ballots into list offsets (8 per lane, a 16-lane DPP scan = one list per slab) and
 //     writes the candidates of its own items;
-//   * the lists hold POSITIONS p = j * 1024 + wave * 64 + lane (item j * 16 + wave of the slab, row `lane` of the item),
+//   * the lists hold POSITIONS p = j * 1024 + wave * 64 + lane (item j of wave `wave`, row `lane` of the item),
 //     ascending; the exact pass translates them through the slab's permutation perm16[slab * 8192 + p] = local row id.
 // The candidate SET is the one k_fr_filter_q8o lists (same table, same threshold, integer sums); only its order differs.
 #include "canopy_device.h"
@@ -28,6 +29,10 @@ namespace canopy {
 namespace {
 
 #define AS1 __attribute__((address_space(1)))
+#ifndef LS_DEPTH
+#define LS_DEPTH 2 // register sets of the unit pipeline: 2 = one unit requested ahead of the adds, 3 = two (measured level: 0.2346
+                   // against 0.2333 ms per step at config 3 -- the pass is not waiting for its loads)
+#endif
 typedef uint32_t ls_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLsSlabRows = 8192, kLsWaves = 16, kLsIPW = 8, kLsStepSlabs = 4, kLsUnitRows = 32, kLsThreads = kLsWaves * kWave;
@@ -42,6 +47,11 @@ struct LsDesc { // one per (step, wave): 16 bytes
     uint32_t bm0;    // index of its first unit in the boundary-mask array
     uint32_t pad;
 };
+
+// The sorted item that is item j of wave w: a serpentine over the 16 waves, so that every wave gets the same share of every
+// length class (with w, w + 16, ... wave 15's eight items are each one class longer than wave 0's: 52 against 44 entry rows
+// per slab at config 3, i.e. seven units against six per step and a barrier that waits for the long ones).
+__host__ __device__ __forceinline__ int ls_item_of(int j, int w) { return j * kLsWaves + ((j & 1) ? kLsWaves - 1 - w : w); }
 
 __device__ __forceinline__ int ls_eff_len(const int64_t* __restrict__ row_ptr, int64_t r, int64_t n_rows) {
     if (r >= n_rows) return 1; // a padding row: one killing entry
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(256) void k_ls_sizes(const int64_t* __restrict__ ro
     __syncthreads();
     if (threadIdx.x < kLsWaves) {
         unsigned n = 0;
-        for (int j = 0; j < kLsIPW; ++j) n += item_len[j * kLsWaves + threadIdx.x];
+        for (int j = 0; j < kLsIPW; ++j) n += item_len[ls_item_of(j, (int)threadIdx.x)];
         sizes[slab * kLsWaves + threadIdx.x] = n;
     }
 }
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(kLsThreads) void k_ls_fill(const int64_t* __restric
             }
         const int slab_max = s_max;
         for (int j = 0; j < kLsIPW; ++j) {
-            const int item = j * kLsWaves + wave;
+            const int item = ls_item_of(j, wave);
             const uint32_t kk = key[item * kWave + lane];
             const uint32_t last = key[item * kWave + kWave - 1] >> 13;
             const int L = last == (uint32_t)kLsKeyMax ? slab_max : (int)last; // (wave-uniform)
@@ -203,15 +213,24 @@ __device__ __forceinline__ const T AS1* ls_uniform_ptr(const T* p) {
     return (const T AS1*)(((uint64_t)hi << 32) | lo);
 }
 
+// base + a wave-uniform byte offset made of values that already sit in scalar registers: the arithmetic stays on the scalar
+// ALU. (Through ls_uniform_ptr's v_readfirstlane of the finished pointer the whole chain -- line index, select, shift, add --
+// ran on the vector ALU, in temporaries that were the destinations of unit loads still in flight: a `s_waitcnt vmcnt(0..2)`
+// in front of every request.)
+template <typename T>
+__device__ __forceinline__ const T AS1* ls_sgpr_ptr(const T* base, uint64_t byte_off) {
+    return (const T AS1*)((uint64_t)base + byte_off);
+}
+
 // a unit: BITS lines of 256 bytes + its boundary mask (a vector load of ONE address: a scalar load would share lgkmcnt with
 // the LDS reads and return out of order, kernels_fr.hip q8_load_chunk)
 template <int BITS>
 __device__ __forceinline__ void ls_load_unit(LsUnit<BITS>& U, const uint32_t* __restrict__ ent, const uint32_t* __restrict__ bm, uint32_t line,
                                              uint32_t bmi, int lane, uint32_t zero) {
-    const uint32_t AS1* p = ls_uniform_ptr(ent + (size_t)line * kWave) + (uint32_t)lane;
+    const uint32_t AS1* p = ls_sgpr_ptr(ent, (uint64_t)line * (kWave * 4)) + (uint32_t)lane;
 #pragma unroll
     for (int q = 0; q < BITS; ++q) U.d[q] = p[q * kWave];
-    const char AS1* bp = reinterpret_cast<const char AS1*>(ls_uniform_ptr(bm + bmi));
+    const char AS1* bp = reinterpret_cast<const char AS1*>(ls_sgpr_ptr(bm, (uint64_t)bmi * 4));
     U.bm = *reinterpret_cast<const uint32_t AS1*>(bp + zero);
 }
 
@@ -242,6 +261,11 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* s_m = reinterpret_cast<unsigned long long*>(smem); // [2][kLsSlots] ballots, slot (ls * 8 + j) * 16 + wave
     uint8_t* tab = reinterpret_cast<uint8_t*>(smem + 2 * kLsSlots * 8);
+    // The table is read at ABSOLUTE LDS addresses (this kernel has no static LDS: its dynamic LDS starts at 0). Through `tab[col]`
+    // every read paid a `v_add_u32 v, 0, v` -- the link-time base of `smem` -- i.e. 32 of the ~110 vector instructions of a unit.
+    typedef const uint8_t __attribute__((address_space(3))) * lds_bytes;
+    if (__builtin_expect((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u, 0)) __builtin_trap();
+    constexpr uint32_t kTabAt = 2 * kLsSlots * 8;
     constexpr uint32_t kColMask = (1u << BITS) - 1u;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -258,7 +282,17 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
     LsDesc d_nxt = ls_load_desc(desc, didx(s_begin + 1), zero_v);
     ls_desc_uniform(d_cur);
     LsUnit<BITS> A, B;
+#if LS_DEPTH == 3
+    LsUnit<BITS> C;
+#endif
     ls_load_unit<BITS>(A, ent, bm, d_cur.line0, d_cur.bm0, lane, zero_v);
+#if LS_DEPTH == 3
+    {
+        const bool two = d_cur.n_rows > (uint32_t)kLsUnitRows;
+        // (zero_line is not known yet: a range of one unit asks for its own lines again)
+        ls_load_unit<BITS>(B, ent, bm, two ? d_cur.line0 + (uint32_t)BITS : d_cur.line0, two ? d_cur.bm0 + 1u : d_cur.bm0, lane, zero_v);
+    }
+#endif
     {
         const uint4* src = reinterpret_cast<const uint4*>(q8);
         uint4* dst = reinterpret_cast<uint4*>(tab);
@@ -267,7 +301,13 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
     for (int i = tid; i < 2 * kLsSlots; i += kLsThreads) s_m[i] = 0ULL;
     // the LDS table's bytes behind the two sentinels are never addressed: every column of the stream is < n_events + 2
     ls_barrier();
-    const LsDesc d_empty = [&] { LsDesc e = ls_load_desc(desc, last, zero_v); ls_desc_uniform(e); return e; }();
+    uint32_t zero_line, zero_bm; // the unit of zero lines behind the stream
+    {
+        LsDesc e = ls_load_desc(desc, last, zero_v);
+        ls_desc_uniform(e);
+        zero_line = e.line0;
+        zero_bm = e.bm0;
+    }
     unsigned long long n_cand = 0;
     uint32_t nz_prev = 0u; // the items of the previous step this wave found candidates in
     int it = 0;
@@ -323,23 +363,26 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
         if (have) {
             unsigned long long* mw = s_m + (it & 1) * kLsSlots + wave;
             const int n_units = (int)((d_cur.n_rows + kLsUnitRows - 1) / kLsUnitRows);
-            const uint32_t line0 = d_cur.line0, bm0 = d_cur.bm0;
+            const uint32_t line0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_cur.line0), bm0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_cur.bm0);
             int jj = 0;
             unsigned sum = 0;
-            // two register sets in ping-pong, the next unit requested before this one's LDS work (a range's last half asks for the
-            // zero lines behind the stream: the number of loads in flight is the same on every path)
+            // two register sets in ping-pong, the next unit requested before this one's LDS work. A range's last half asks for the
+            // zero lines behind the stream (a cached unit): the same number of loads in flight on every path. (Asking for the lines
+            // that FOLLOW the range instead -- no select on the way to the address -- costs 10 % of the step: 0.259 against 0.236
+            // ms, the next wave's first unit fetched twice.)
 #define LS_HALF(UC, UN, UI)                                                                                                  \
             {                                                                                                                \
-                const bool more = (UI) + 1 < n_units;                                                                        \
-                ls_load_unit<BITS>(UN, ent, bm, more ? line0 + (uint32_t)((UI) + 1) * BITS : d_empty.line0,                  \
-                                   more ? bm0 + (uint32_t)(UI) + 1u : d_empty.bm0, lane, zero_v);                            \
+                const bool more = (UI) + (LS_DEPTH - 1) < n_units;                                                           \
+                uint32_t ln = more ? line0 + (uint32_t)((UI) + (LS_DEPTH - 1)) * BITS : zero_line;                           \
+                uint32_t bn = more ? bm0 + (uint32_t)(UI) + (uint32_t)(LS_DEPTH - 1) : zero_bm;                              \
+                ls_load_unit<BITS>(UN, ent, bm, ln, bn, lane, zero_v);                                                       \
                 unsigned v[kLsUnitRows];                                                                                     \
                 _Pragma("unroll") for (int t = 0; t < kLsUnitRows; ++t) {                                                    \
                     const int bo = t * BITS, w = bo >> 5, sh = bo & 31;                                                      \
                     uint32_t col;                                                                                            \
                     if (sh + BITS <= 32) col = __builtin_amdgcn_ubfe(UC.d[w], (uint32_t)sh, (uint32_t)BITS);                 \
                     else col = __builtin_amdgcn_alignbit(UC.d[w + 1 < BITS ? w + 1 : w], UC.d[w], (uint32_t)sh) & kColMask;  \
-                    v[t] = tab[col];                                                                                         \
+                    v[t] = *(lds_bytes)(uintptr_t)(col + kTabAt);                                                            \
                 }                                                                                                            \
                 const uint32_t bmv = (uint32_t)__builtin_amdgcn_readfirstlane((int)UC.bm);                                   \
                 _Pragma("unroll") for (int t = 0; t < kLsUnitRows; ++t) {                                                    \
@@ -353,6 +396,19 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
                     }                                                                                                        \
                 }                                                                                                            \
             }
+#if LS_DEPTH == 3
+            // (unit 1 of this step is in B since the end of the previous step)
+            for (int u = 0; u < n_units;) {
+                LS_HALF(A, C, u)
+                ++u;
+                if (u >= n_units) break;
+                LS_HALF(B, A, u)
+                ++u;
+                if (u >= n_units) break;
+                LS_HALF(C, B, u)
+                ++u;
+            }
+#else
             for (int u = 0; u < n_units;) {
                 LS_HALF(A, B, u)
                 ++u;
@@ -360,11 +416,18 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
                 LS_HALF(B, A, u)
                 ++u;
             }
+#endif
 #undef LS_HALF
         }
-        // the next step's first unit goes out before this step's barrier (always into A)
+        // the next step's first unit(s) go out before this step's barrier (always into A, B)
         ls_desc_uniform(d_nxt);
         ls_load_unit<BITS>(A, ent, bm, d_nxt.line0, d_nxt.bm0, lane, zero_v);
+#if LS_DEPTH == 3
+        {
+            const bool two = d_nxt.n_rows > (uint32_t)kLsUnitRows;
+            ls_load_unit<BITS>(B, ent, bm, two ? d_nxt.line0 + (uint32_t)BITS : zero_line, two ? d_nxt.bm0 + 1u : zero_bm, lane, zero_v);
+        }
+#endif
         d_cur = d_nxt;
         d_nxt = d_nn;
         nz_prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)nz_now);
