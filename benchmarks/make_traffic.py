@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the PMC passes of benchmarks/pmc.sh into profiles/traffic*.json: HBM bytes per launch of a two-kernel pass
-(FILTER_REFINE: k_fr_filter_q8 + k_fr_refine<false>; FIXED_SUM: k_fx2 + k_fr_refine<true>), corrected as
+(FILTER_REFINE: k_fr_filter_ls / k_fr_filter_q8o + k_fr_refine<false, ..>; FIXED_SUM: k_fx2 + k_fr_refine<true, ..>), corrected as
 MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE (KiB) x 1024 x 2 (gfx950 tallies the 128-byte requests of a
 wide coalesced stream at 64 bytes), WRITE_SIZE (KiB) x 1024 as read.
 usage: make_traffic.py <pmc outdir> <out json> [rows events cut_off variant round]"""
@@ -19,7 +19,7 @@ def main():
     cut_off = float(sys.argv[5]) if len(sys.argv) > 5 else 1e-8
     variant = int(sys.argv[6]) if len(sys.argv) > 6 else 5
     rnd = int(sys.argv[7]) if len(sys.argv) > 7 else 2
-    kernels = ("k_fr_filter_q8", "k_fr_refine<false>") if variant == 5 else ("k_fx2", "k_fr_refine<true>")
+    kernels = ("k_fr_filter_", "k_fr_refine<false") if variant == 5 else ("k_fx2", "k_fr_refine<true")  # (k_fr_filter_ls<17>, k_fr_refine<false, true> with the row stream)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     seen = {}  # the kernels' names as the profiler reports them (k_fr_filter_q8o<4> ...)
     for f in glob.glob(out_dir + "/p*/**/*counter_collection.csv", recursive=True):

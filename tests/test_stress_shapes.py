@@ -231,3 +231,34 @@ def test_band_stream_is_auto_for_per_row_output_and_takes_long_rows(gpu_ctx, ora
     gpu_ctx.quantify(wide, default_params(flags=_capi.QUANT_ROW_LOGP))
     assert gpu_ctx.last_kernel_variant() != _capi.KERNEL_BAND_STREAM
     wide.close()
+
+
+@pytest.mark.parametrize("n_events", [3000, 70_000])
+def test_row_stream_of_the_quantised_filter(gpu_ctx, oracle, n_events):
+    """The quantised filter's row stream (kernels_ls.hip): rows sorted by length inside every slab, 16- or 17-bit columns,
+    lists of positions that the exact pass translates. Two steps of four slabs, a third with one full slab and a partial
+    one; lengths 0 .. 12 with a few rows of 40, 300 and 1000 entries (the class of 255 and more); the best row twice
+    (the argmax tie goes to the lower row although the list does not ascend in rows); keep mask and sums against the
+    oracle for every variant."""
+    from canopy_amd import _capi
+    rng = np.random.default_rng(77 + n_events)
+    n_rows = 9 * 8192 + 777
+    rows = random_rows(rng, n_rows, 0, n_events, 12)
+    for r, k in ((5, 40), (8191, 300), (8192, 1000), (40_000, 300), (n_rows - 1, 40)):
+        rows[r] = sorted(int(c) for c in rng.choice(n_events, size=k, replace=False))
+    p = 10.0 ** rng.uniform(-3.0, -0.3, size=n_events)
+    best = [int(np.argmax(p))]
+    rows[60_000] = best
+    rows[123] = best      # the same (largest) probability twice: row 123 is the argmax
+    rows[9000] = []       # an empty cut set is kept whatever the cut-off
+    row_ptr, col = csr_from_rows(rows)
+    model = gpu_ctx.upload(row_ptr, col, n_events)
+    model.prepare(_capi.KERNEL_FILTER_REFINE)
+    info = model.info()
+    assert info.stream_bytes_rows > 0
+    # (bits / 8) bytes per entry + the padding of the items that hold the long rows + descriptors, masks, the table once
+    assert info.stream_bytes_rows < (2.2 if n_events > 65534 else 2.1) * int(row_ptr[-1]) + 64 * (1000 + 300 + 300 + 40 + 40) * 2.2 + 8 * n_events + 65536
+    model.close()
+    for cut_off in (1e-6, 1e-3):
+        check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, cut_off, 20)
+    check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, 1e-4, 3)  # limit_order below most rows
