@@ -495,12 +495,14 @@ __global__ __launch_bounds__(256) void k_fr_q8_table(const double* __restrict__ 
 __global__ __launch_bounds__(256) void k_fr_q4_table(const double* __restrict__ logp, int32_t n_events, double inv_step,
                                                      uint8_t* __restrict__ q4) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (2 * b >= n_events) return;
+    if (2 * b >= n_events + 2) return;
     unsigned v = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int j = 2 * b + h;
-        unsigned q = 15u; // (the odd slot past the last event is never read)
+        // behind the last event: the row stream's two sentinel columns (kernels_ls.hip) -- a padding entry (0), a row past the
+        // model's end (15: alone enough to kill it); the chunk filter reads neither
+        unsigned q = j == n_events ? 0u : 15u;
         if (j < n_events) {
             const double lv = -logp[j] * inv_step * (1.0 - 0x1.0p-30); // as in k_fr_q8_table: a lower bound
             q = lv >= 15.0 ? 15u : (unsigned)(int)lv;
@@ -1920,7 +1922,7 @@ void fr_q8_overlapped_units(int* unit_rows, int* units_per_slab) { *unit_rows = 
 hipError_t launch_fr_q8_table(const double* logp, int32_t n_events, double log_cut, uint8_t* q8_buf, hipStream_t s) {
     const double mag = -log_cut > 1.0 ? -log_cut : 1.0;
     if (fr_q8_nibble(n_events)) {
-        hipLaunchKernelGGL(k_fr_q4_table, dim3(grid_for((n_events + 1) / 2, 256)), dim3(256), 0, s, logp, n_events, (double)kQ4Levels / mag, q8_buf);
+        hipLaunchKernelGGL(k_fr_q4_table, dim3(grid_for((n_events + 3) / 2, 256)), dim3(256), 0, s, logp, n_events, (double)kQ4Levels / mag, q8_buf);
         return hipGetLastError();
     }
     const double inv_step = (double)kQ8Levels / mag;
@@ -1943,8 +1945,8 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
         e = launch_fr_q8_table(logp, n_events, log_cut, q8_buf, s);
         if (e != hipSuccess) return e;
     }
-    if (ls != nullptr && !nib) // the row stream (kernels_ls.hip): the same table and threshold, lists of positions
-        return launch_ls_filter(*ls, q8_buf, n_events, threshold, cand_list, cand_cnt, cand_count, n_cu, s);
+    if (ls != nullptr) // the row stream (kernels_ls.hip): the same table and threshold, lists of positions
+        return launch_ls_filter(*ls, q8_buf, n_events, nib, threshold, cand_list, cand_cnt, cand_count, n_cu, s);
     static const int u = CANOPY_TUNE_ENV("CANOPY_FR_QU") ? atoi(CANOPY_TUNE_ENV("CANOPY_FR_QU")) : 4; // tuning only (chunks in flight per wave)
     static const int fr_dbg = CANOPY_TUNE_ENV("CANOPY_FR_DEBUG") ? atoi(CANOPY_TUNE_ENV("CANOPY_FR_DEBUG")) : 0; // timing ablations only
     const int H = fr_parts_for(n_events);

@@ -1,4 +1,4 @@
-// kernels_ls.hip -- the ROW STREAM of the quantised filter (pass A of FILTER_REFINE, E <= 112 K), gfx950 / wave64 only.
+// kernels_ls.hip -- the ROW STREAM of the quantised filter (pass A of FILTER_REFINE, E <= 260 096), gfx950 / wave64 only.
 //
 // The quantised filter (kernels_fr.hip, k_fr_filter_q8o) reads a column-sorted slab stream of 3-byte entries (row 13 bits |
 // column offset 11 bits) and scatters one LDS atomic per entry into the slab's row sums. Its sums are small integers: the
@@ -8,7 +8,7 @@
 //     length L is L "entry rows": the lane's k-th column, k < L (rows shorter than their item are padded with a column
 //     whose table value is 0, the rows past the model's end carry a column whose value kills them) -- no row ids in the
 //     stream at all;
-//   * a lane's columns are a bit stream of BITS = 17 (16 up to 65534 events) bits per entry; 32 entry rows = BITS dwords
+//   * a lane's columns are a bit stream of BITS = 17 (16 up to 65534 events) bits per entry -- 12 / 14 / 16 / 17 / 18 by the number of events --; 32 entry rows = BITS dwords
 //     per lane = one UNIT of BITS 256-byte lines: 2.125 bytes per entry instead of 3.03;
 //   * the sorted items of a slab go to the 16 waves in a serpentine (every wave gets the same share of every length class:
 //     ls_item_of); the 8 items a wave has in each
@@ -38,7 +38,8 @@ typedef uint32_t ls_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kLsSlabRows = 8192, kLsWaves = 16, kLsIPW = 8, kLsStepSlabs = 4, kLsUnitRows = 32, kLsThreads = kLsWaves * kWave;
 constexpr int kLsItems = kLsIPW * kLsStepSlabs;          // items of a wave per step
 constexpr int kLsSlots = kLsItems * kLsWaves;            // ballots of a step
-constexpr int kLsMaxEvents = 112 * 1024;                 // (the 8-bit table's own limit, kernels_fr.hip)
+constexpr int kLsMaxEvents8 = 112 * 1024;                // the 8-bit table's limit, as the chunk filter's (kernels_fr.hip kQ8MaxEvents)
+constexpr int kLsMaxEvents4 = 260096;                    // the 4-bit table's (kQ4MaxEvents): two events per byte, levels 0 .. 14, 15 kills
 constexpr int kLsKeyMax = 255;                           // rows of >= 255 entries sort as one class
 
 struct LsDesc { // one per (step, wave): 16 bytes
@@ -253,7 +254,8 @@ __device__ __forceinline__ unsigned ls_row_shr_add(unsigned x) {
     return x + (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
 }
 
-template <int BITS>
+// NIB: the table holds four bits per event (112 K < E <= 260 096, as the chunk filter's: k_fr_q4_table)
+template <int BITS, bool NIB>
 __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __restrict__ ent, const uint32_t* __restrict__ bm,
                                                               const LsDesc* __restrict__ desc, const uint8_t* __restrict__ q8, int32_t n_events,
                                                               int64_t n_steps, int64_t n_slabs, int threshold, uint16_t* __restrict__ cand_list,
@@ -296,7 +298,8 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
     {
         const uint4* src = reinterpret_cast<const uint4*>(q8);
         uint4* dst = reinterpret_cast<uint4*>(tab);
-        for (int i = tid; i < (n_events + 2 + 15) / 16; i += kLsThreads) dst[i] = src[i];
+        const int tab_bytes = NIB ? (n_events + 3) / 2 : n_events + 2; // (+ the two sentinels)
+        for (int i = tid; i < (tab_bytes + 15) / 16; i += kLsThreads) dst[i] = src[i];
     }
     for (int i = tid; i < 2 * kLsSlots; i += kLsThreads) s_m[i] = 0ULL;
     // the LDS table's bytes behind the two sentinels are never addressed: every column of the stream is < n_events + 2
@@ -382,7 +385,8 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
                     uint32_t col;                                                                                            \
                     if (sh + BITS <= 32) col = __builtin_amdgcn_ubfe(UC.d[w], (uint32_t)sh, (uint32_t)BITS);                 \
                     else col = __builtin_amdgcn_alignbit(UC.d[w + 1 < BITS ? w + 1 : w], UC.d[w], (uint32_t)sh) & kColMask;  \
-                    v[t] = *(lds_bytes)(uintptr_t)(col + kTabAt);                                                            \
+                    if (NIB) v[t] = ((unsigned)*(lds_bytes)(uintptr_t)((col >> 1) + kTabAt) >> ((col & 1u) << 2)) & 15u;            \
+                    else v[t] = *(lds_bytes)(uintptr_t)(col + kTabAt);                                                       \
                 }                                                                                                            \
                 const uint32_t bmv = (uint32_t)__builtin_amdgcn_readfirstlane((int)UC.bm);                                   \
                 _Pragma("unroll") for (int t = 0; t < kLsUnitRows; ++t) {                                                    \
@@ -443,9 +447,13 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 bool ls_applies(int32_t n_events) {
     static const bool off = CANOPY_TUNE_ENV("CANOPY_FR_NOLS") != nullptr; // tuning only
-    return !off && n_events >= 1 && n_events <= kLsMaxEvents;
+    return !off && n_events >= 1 && n_events <= kLsMaxEvents4;
 }
-int ls_bits_for(int32_t n_events) { return n_events + 2 <= 65536 ? 16 : 17; }
+// bits per entry: the columns 0 .. n_events + 1 (two sentinels) must fit
+int ls_bits_for(int32_t n_events) {
+    const int64_t c = (int64_t)n_events + 2;
+    return c <= 4096 ? 12 : (c <= 16384 ? 14 : (c <= 65536 ? 16 : (c <= 131072 ? 17 : 18)));
+}
 
 void ls_free(LsOwned* L) {
     if (L->ent) (void)hipFree(L->ent);
@@ -514,12 +522,17 @@ hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
                        (const uint32_t*)d_rows, n_ranges, reinterpret_cast<LsDesc*>(L.desc));
     e = hipGetLastError();
     if (e != hipSuccess) return bail(e);
-    if (bits == 16)
-        hipLaunchKernelGGL(k_ls_fill<16>, dim3((unsigned)n_steps), dim3(kLsThreads), 0, s, d_row_ptr, d_col_idx, n_rows, n_events, n_slabs,
-                           reinterpret_cast<const LsDesc*>(L.desc), L.ent, L.bm, L.perm16);
-    else
-        hipLaunchKernelGGL(k_ls_fill<17>, dim3((unsigned)n_steps), dim3(kLsThreads), 0, s, d_row_ptr, d_col_idx, n_rows, n_events, n_slabs,
-                           reinterpret_cast<const LsDesc*>(L.desc), L.ent, L.bm, L.perm16);
+#define LS_FILL(B)                                                                                                         \
+    hipLaunchKernelGGL(k_ls_fill<B>, dim3((unsigned)n_steps), dim3(kLsThreads), 0, s, d_row_ptr, d_col_idx, n_rows, n_events, n_slabs, \
+                       reinterpret_cast<const LsDesc*>(L.desc), L.ent, L.bm, L.perm16)
+    switch (bits) {
+        case 12: LS_FILL(12); break;
+        case 14: LS_FILL(14); break;
+        case 16: LS_FILL(16); break;
+        case 17: LS_FILL(17); break;
+        default: LS_FILL(18); break;
+    }
+#undef LS_FILL
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return bail(e);
@@ -531,29 +544,42 @@ hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     return hipSuccess;
 }
 
-size_t ls_filter_lds(int32_t n_events) { return (size_t)2 * kLsSlots * 8 + (((size_t)n_events + 2 + 15) / 16) * 16; }
+size_t ls_filter_lds(int32_t n_events, bool nib) {
+    const size_t tab = nib ? ((size_t)n_events + 3) / 2 : (size_t)n_events + 2;
+    return (size_t)2 * kLsSlots * 8 + ((tab + 15) / 16) * 16;
+}
 
-// q8: the 8-bit table of the pass with its two sentinels behind it (launch_fr_q8_table)
-hipError_t launch_ls_filter(const LsView& L, const uint8_t* q8, int32_t n_events, int threshold, uint16_t* cand_list, unsigned* cand_cnt,
+// q8: the table of the pass (8 bits per event, or 4: nib) with its two sentinels behind it (launch_fr_q8_table)
+hipError_t launch_ls_filter(const LsView& L, const uint8_t* q8, int32_t n_events, bool nib, int threshold, uint16_t* cand_list, unsigned* cand_cnt,
                             unsigned long long* cand_count, int n_cu, hipStream_t s) {
-    const size_t lds = ls_filter_lds(n_events);
+    const size_t lds = ls_filter_lds(n_events, nib);
+    if (lds > (size_t)160 * 1024 || (!nib && n_events > kLsMaxEvents8)) return hipErrorInvalidValue;
     static const int forced = CANOPY_TUNE_ENV("CANOPY_LS_GRID") ? atoi(CANOPY_TUNE_ENV("CANOPY_LS_GRID")) : 0; // tuning only
     int64_t g = forced > 0 ? forced : n_cu;
     if (g > L.n_steps) g = L.n_steps;
     if (g < 1) g = 1;
     const LsDesc* desc = reinterpret_cast<const LsDesc*>(L.desc);
-    if (L.bits == 16) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fr_filter_ls<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(k_fr_filter_ls<16>, dim3((unsigned)g), dim3(kLsThreads), lds, s, L.ent, L.bm, desc, q8, n_events, L.n_steps, L.n_slabs, threshold,
-                           cand_list, cand_cnt, cand_count);
-    } else {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fr_filter_ls<17>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(k_fr_filter_ls<17>, dim3((unsigned)g), dim3(kLsThreads), lds, s, L.ent, L.bm, desc, q8, n_events, L.n_steps, L.n_slabs, threshold,
-                           cand_list, cand_cnt, cand_count);
+#define LS_GO(B, N)                                                                                                             \
+    do {                                                                                                                        \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fr_filter_ls<B, N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (attr != hipSuccess) return attr;                                                                                    \
+        hipLaunchKernelGGL((k_fr_filter_ls<B, N>), dim3((unsigned)g), dim3(kLsThreads), lds, s, L.ent, L.bm, desc, q8, n_events, L.n_steps, L.n_slabs, \
+                           threshold, cand_list, cand_cnt, cand_count);                                                         \
+        return hipGetLastError();                                                                                               \
+    } while (0)
+    if (nib) {
+        if (L.bits == 17) LS_GO(17, true);
+        if (L.bits == 18) LS_GO(18, true);
+        return hipErrorInvalidValue; // (the 4-bit table is for more than 112 K events)
     }
-    return hipGetLastError();
+    switch (L.bits) {
+        case 12: LS_GO(12, false);
+        case 14: LS_GO(14, false);
+        case 16: LS_GO(16, false);
+        case 17: LS_GO(17, false);
+        default: return hipErrorInvalidValue;
+    }
+#undef LS_GO
 }
 
 } // namespace canopy

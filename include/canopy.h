@@ -175,8 +175,8 @@ typedef struct canopy_model_info {
                                    4 B per entry in 1 KiB chunks + chunk offsets + the fixed-point table once), 0 without a slab stream */
     int64_t stream_bytes_exact; /* bytes one pass of the exact all-rows stream kernel reads (the band stream when the model has
                                    one, else the wave-slab stream; entries + offsets + the logp table once), 0 if neither is built */
-    int64_t stream_bytes_rows;  /* bytes the quantised filter of FILTER_REFINE reads when the model has a ROW STREAM (up to 112 K
-                                   events: 17 or 16 bits per entry in length-sorted rows, no row ids; range descriptors, item-end
+    int64_t stream_bytes_rows;  /* bytes the quantised filter of FILTER_REFINE reads when the model has a ROW STREAM (up to 260 096
+                                   events: 12 .. 18 bits per entry in length-sorted rows, no row ids; range descriptors, item-end
                                    masks, the logp table once), 0 without one -- a sum-only FILTER_REFINE pass then reads
                                    stream_bytes. Its lists hold positions: the exact pass reads one more 128-byte line per listed
                                    row (the slab's permutation) */

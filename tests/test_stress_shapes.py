@@ -233,10 +233,11 @@ def test_band_stream_is_auto_for_per_row_output_and_takes_long_rows(gpu_ctx, ora
     wide.close()
 
 
-@pytest.mark.parametrize("n_events", [3000, 70_000])
+@pytest.mark.parametrize("n_events", [3000, 10_000, 40_000, 70_000, 120_000, 200_000])
 def test_row_stream_of_the_quantised_filter(gpu_ctx, oracle, n_events):
-    """The quantised filter's row stream (kernels_ls.hip): rows sorted by length inside every slab, 16- or 17-bit columns,
-    lists of positions that the exact pass translates. Two steps of four slabs, a third with one full slab and a partial
+    """The quantised filter's row stream (kernels_ls.hip): rows sorted by length inside every slab, columns of 12 / 14 / 16 /
+    17 bits (8-bit table) and 17 / 18 bits (4-bit table, more than 112 K events), lists of positions that the exact pass
+    translates. Two steps of four slabs, a third with one full slab and a partial
     one; lengths 0 .. 12 with a few rows of 40, 300 and 1000 entries (the class of 255 and more); the best row twice
     (the argmax tie goes to the lower row although the list does not ascend in rows); keep mask and sums against the
     oracle for every variant."""
@@ -257,7 +258,8 @@ def test_row_stream_of_the_quantised_filter(gpu_ctx, oracle, n_events):
     info = model.info()
     assert info.stream_bytes_rows > 0
     # (bits / 8) bytes per entry + the padding of the items that hold the long rows + descriptors, masks, the table once
-    assert info.stream_bytes_rows < (2.2 if n_events > 65534 else 2.1) * int(row_ptr[-1]) + 64 * (1000 + 300 + 300 + 40 + 40) * 2.2 + 8 * n_events + 65536
+    bits = 12 if n_events + 2 <= 4096 else 14 if n_events + 2 <= 16384 else 16 if n_events + 2 <= 65536 else 17 if n_events + 2 <= 131072 else 18
+    assert info.stream_bytes_rows < (bits / 8 + 0.1) * int(row_ptr[-1]) + 64 * (1000 + 300 + 300 + 40 + 40) * 2.3 + 8 * n_events + 65536
     model.close()
     for cut_off in (1e-6, 1e-3):
         check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, cut_off, 20)
