@@ -29,6 +29,10 @@ namespace canopy {
 namespace {
 
 #define AS1 __attribute__((address_space(1)))
+#ifndef LS_ABL
+#define LS_ABL 0 // timing ablations (WRONG results, benchmarks/build_ls_variant.sh only): 1 = table reads at conflict-free addresses
+                 // (other table entries: the filter then misses survivors), 2 = a stream whose columns are conflict-free by construction
+#endif
 #ifndef LS_DEPTH
 #define LS_DEPTH 2 // register sets of the unit pipeline: 2 = one unit requested ahead of the adds, 3 = two (measured level: 0.2346
                    // against 0.2333 ms per step at config 3 -- the pass is not waiting for its loads)
@@ -178,7 +182,11 @@ __global__ __launch_bounds__(kLsThreads) void k_ls_fill(const int64_t* __restric
             const int64_t b = real ? row_ptr[r] : 0;
             const int len = real ? (int)(row_ptr[r + 1] - b) : 0;
             for (int k = 0; k < L; ++k) {
-                const uint32_t col = real ? (k < len ? (uint32_t)col_idx[b + k] : pad_col) : kill_col;
+                uint32_t col = real ? (k < len ? (uint32_t)col_idx[b + k] : pad_col) : kill_col;
+                if (LS_ABL == 2 && real && k < len) { // timing ablation (WRONG results): every lane of a half on a bank of its own
+                    const uint64_t h = mix64(((uint64_t)r << 8) | (uint64_t)k);
+                    col = (uint32_t)(h % (uint64_t)(n_events / 128)) * 128u + (uint32_t)(lane & 31) * 4u + (uint32_t)((h >> 40) & 3u);
+                }
                 acc |= (uint64_t)col << nb;
                 nb += BITS;
                 if (nb >= 32) { ent[((size_t)d.line0 + dw) * kWave + lane] = (uint32_t)acc; acc >>= 32; nb -= 32; ++dw; }
@@ -385,6 +393,7 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
                     uint32_t col;                                                                                            \
                     if (sh + BITS <= 32) col = __builtin_amdgcn_ubfe(UC.d[w], (uint32_t)sh, (uint32_t)BITS);                 \
                     else col = __builtin_amdgcn_alignbit(UC.d[w + 1 < BITS ? w + 1 : w], UC.d[w], (uint32_t)sh) & kColMask;  \
+                    if (LS_ABL == 1) col = (col & ~127u) | ((uint32_t)lane << 2); /* timing ablation: no two lanes of a half on one bank */ \
                     if (NIB) v[t] = ((unsigned)*(lds_bytes)(uintptr_t)((col >> 1) + kTabAt) >> ((col & 1u) << 2)) & 15u;            \
                     else v[t] = *(lds_bytes)(uintptr_t)(col + kTabAt);                                                       \
                 }                                                                                                            \
