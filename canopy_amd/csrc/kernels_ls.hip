@@ -31,7 +31,8 @@ namespace {
 #define AS1 __attribute__((address_space(1)))
 #ifndef LS_ABL
 #define LS_ABL 0 // timing ablations (WRONG results, benchmarks/build_ls_variant.sh only): 1 = table reads at conflict-free addresses
-                 // (other table entries: the filter then misses survivors), 2 = a stream whose columns are conflict-free by construction
+                 // (other table entries: the filter then misses survivors), 2 = a stream whose columns are conflict-free by construction,
+                 // 3 = no table read (the low byte of the column instead), 4 = no list written
 #endif
 #ifndef LS_DEPTH
 #define LS_DEPTH 2 // register sets of the unit pipeline: 2 = one unit requested ahead of the adds, 3 = two (measured level: 0.2346
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
                     if (sh + BITS <= 32) col = __builtin_amdgcn_ubfe(UC.d[w], (uint32_t)sh, (uint32_t)BITS);                 \
                     else col = __builtin_amdgcn_alignbit(UC.d[w + 1 < BITS ? w + 1 : w], UC.d[w], (uint32_t)sh) & kColMask;  \
                     if (LS_ABL == 1) col = (col & ~127u) | ((uint32_t)lane << 2); /* timing ablation: no two lanes of a half on one bank */ \
-                    if (NIB) v[t] = ((unsigned)*(lds_bytes)(uintptr_t)((col >> 1) + kTabAt) >> ((col & 1u) << 2)) & 15u;            \
+                    if (LS_ABL == 3) v[t] = col & 255u; /* timing ablation: no table read at all */                                  \
+                    else if (NIB) v[t] = ((unsigned)*(lds_bytes)(uintptr_t)((col >> 1) + kTabAt) >> ((col & 1u) << 2)) & 15u;            \
                     else v[t] = *(lds_bytes)(uintptr_t)(col + kTabAt);                                                       \
                 }                                                                                                            \
                 const uint32_t bmv = (uint32_t)__builtin_amdgcn_readfirstlane((int)UC.bm);                                   \
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
 #endif
         d_cur = d_nxt;
         d_nxt = d_nn;
-        nz_prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)nz_now);
+        nz_prev = LS_ABL == 4 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)nz_now); // (ablation 4: no list is written)
         s_emit = have ? s : -1;
         if (!have) break; // nothing left in flight: nobody reads anything of ours any more
         ls_barrier();
