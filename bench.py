@@ -531,6 +531,10 @@ def main():
                         "folded into the next iterations; then exact refine)")
     if variant == 5 and info.n_events > 112 * 1024:
         kernel_label = "k_fr_filter_q8p + k_fr_refine (quantised filter, one column part of the table resident per sweep; then exact refine)"
+    if variant == 5 and getattr(info, "stream_bytes_rows", 0):
+        kernel_label = ("k_fr_filter_ls + k_fr_refine (quantised conservative filter over the ROW STREAM -- rows sorted by length inside every "
+                        "8192-row slab, one row per lane, 12 .. 18-bit columns, no row ids; lists of positions -- then exact refine of the "
+                        "listed rows through the slab's permutation)")
 
     info = model.info()  # (before the all-rows leg adds its own layout to device_bytes)
     k_mean, k_med, k_min = stats([a for a, _ in launches])
@@ -728,9 +732,9 @@ def main():
                 "frac_pmc": (traffic / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "canonical_equivalent_gbs": info.algorithmic_bytes / (k_med * 1e-3) / 1e9,
                 "canonical_equivalent_frac": info.algorithmic_bytes / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "achieved / frac = bytes the pass MUST move in the layout it reads (moved_bytes_per_launch: the slab stream "
-                        "in the form the conservative kernel streams it -- stream_bytes_per_launch -- plus two 128-B lines and a "
-                        "list entry per row handed to the exact pass, from this run's live count) / MEDIAN kernel time of the "
+                "note": "achieved / frac = bytes the pass MUST move in the layout it reads (moved_bytes_per_launch: the stream "
+                        "the conservative kernel reads -- stream_bytes_per_launch: the row stream, else the slab stream -- plus three "
+                        "(row stream; else two) 128-B lines and a list entry per row handed to the exact pass, from this run's live count) / MEDIAN kernel time of the "
                         "instrumented serial probe / 8 TB/s; traffic / frac_pmc = the PMC-measured HBM bytes of the same workload "
                         "(profiles/traffic*.json, rocprofv3 --pmc passes) over the same time; canonical_equivalent_* = SURVEY 8(d)'s "
                         "32 B-per-cut-set figure of the canonical CSR over the same time: an equivalent rate, not bytes moved (it "

@@ -439,7 +439,8 @@ struct LsView {
 };
 bool ls_applies(int32_t n_events);
 void ls_free(LsOwned* L);
-hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events, LsOwned* out, bool* ok, hipStream_t s);
+hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int64_t nnz, int32_t n_events, LsOwned* out, bool* ok,
+                    hipStream_t s);
 hipError_t launch_ls_filter(const LsView& L, const uint8_t* q8, int32_t n_events, bool nib, int threshold, uint16_t* cand_list, unsigned* cand_cnt,
                             unsigned long long* cand_count, int n_cu, hipStream_t s);
 hipError_t launch_fr_q8_table(const double* logp, int32_t n_events, double log_cut, uint8_t* q8_buf, hipStream_t s);

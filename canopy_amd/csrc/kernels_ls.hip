@@ -476,7 +476,8 @@ void ls_free(LsOwned* L) {
 
 // Builds the row stream of a model (waits for the stream). *ok = false: the model has no such layout (no rows, too many
 // events, a range too long for its 32-bit counters) -- not an error.
-hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int32_t n_events, LsOwned* out, bool* ok, hipStream_t s) {
+hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int64_t nnz, int32_t n_events, LsOwned* out, bool* ok,
+                    hipStream_t s) {
     *ok = false;
     *out = LsOwned();
     if (!ls_applies(n_events) || n_rows < 1) return hipSuccess;
@@ -516,6 +517,13 @@ hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     if (e != hipSuccess) return bail(e);
     // 32-bit line and unit indices; a range of >= 2^32 entry rows cannot be described (a model of absurdly long rows)
     if (total_lines + 2 * bits >= (int64_t)0xffffffffLL || total_units + 2 >= (int64_t)0xffffffffLL) { (void)bail(hipSuccess); return hipSuccess; }
+    // An item is as long as its longest row: a few rows of thousands of entries among short ones pad their items (64 rows each).
+    // A model whose stream would be more than twice its entries (+ a line per range and the padding rows of the last slab) keeps
+    // the chunk stream: the filter must not read more than it saves.
+    {
+        const int64_t ideal_lines = (int64_t)(((__int128)(nnz + n_slabs * kLsSlabRows - n_rows) * bits + 2047) / 2048);
+        if (total_lines > 2 * ideal_lines + 2 * n_ranges) { (void)bail(hipSuccess); return hipSuccess; }
+    }
     L.n_lines = total_lines + 2 * bits; // (a unit of zero lines behind the stream: what a range's last half and an idle wave request)
     L.n_units = total_units + 1;
     L.n_steps = n_steps;

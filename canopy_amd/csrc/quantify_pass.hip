@@ -117,7 +117,7 @@ canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m) {
     // (optional: the pass runs on the chunks without it)
     if (m->ls_state == 0) {
         bool ls_ok = false;
-        e = ls_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, &m->ls, &ls_ok, ctx->stream);
+        e = ls_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->nnz, m->n_events, &m->ls, &ls_ok, ctx->stream);
         if (e != hipSuccess) { (void)hipGetLastError(); ls_ok = false; }
         m->ls_state = ls_ok ? 1 : -1;
         if (ls_ok) m->device_bytes += m->ls.device_bytes;

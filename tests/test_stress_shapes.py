@@ -264,3 +264,22 @@ def test_row_stream_of_the_quantised_filter(gpu_ctx, oracle, n_events):
     for cut_off in (1e-6, 1e-3):
         check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, cut_off, 20)
     check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, 1e-4, 3)  # limit_order below most rows
+
+
+def test_row_stream_gives_way_to_the_chunks_when_one_long_row_would_pad_it(gpu_ctx, oracle):
+    """An item of the row stream is as long as its longest row: one row of 5000 entries among 20000 rows of two would make
+    the stream seven times the model's entries. Such a model keeps the column-sorted chunks (stream_bytes_rows == 0) and
+    gives the same results."""
+    from canopy_amd import _capi
+    rng = np.random.default_rng(5)
+    n_events = 20_000
+    rows = [sorted(int(c) for c in rng.choice(n_events, size=2, replace=False)) for _ in range(20_000)]
+    rows[777] = sorted(int(c) for c in rng.choice(n_events, size=5000, replace=False))
+    row_ptr, col = csr_from_rows(rows)
+    p = 10.0 ** rng.uniform(-3.0, -0.3, size=n_events)
+    model = gpu_ctx.upload(row_ptr, col, n_events)
+    model.prepare(_capi.KERNEL_FILTER_REFINE)
+    info = model.info()
+    assert info.stream_bytes_rows == 0 and info.stream_bytes > 0
+    model.close()
+    check_against_oracle(gpu_ctx, oracle, row_ptr, col, p, n_events, 1e-4, 20)
