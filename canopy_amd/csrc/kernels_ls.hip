@@ -34,15 +34,19 @@ namespace {
                  // (other table entries: the filter then misses survivors), 2 = a stream whose columns are conflict-free by construction,
                  // 3 = no table read (the low byte of the column instead), 4 = no list written
 #endif
+#ifndef LS_SS
+#define LS_SS 4 // slabs per step (one workgroup barrier per step): 4 or 8
+#endif
 #ifndef LS_DEPTH
 #define LS_DEPTH 2 // register sets of the unit pipeline: 2 = one unit requested ahead of the adds, 3 = two (measured level: 0.2346
                    // against 0.2333 ms per step at config 3 -- the pass is not waiting for its loads)
 #endif
 typedef uint32_t ls_u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kLsSlabRows = 8192, kLsWaves = 16, kLsIPW = 8, kLsStepSlabs = 4, kLsUnitRows = 32, kLsThreads = kLsWaves * kWave;
+constexpr int kLsSlabRows = 8192, kLsWaves = 16, kLsIPW = 8, kLsStepSlabs = LS_SS, kLsUnitRows = 32, kLsThreads = kLsWaves * kWave;
 constexpr int kLsItems = kLsIPW * kLsStepSlabs;          // items of a wave per step
 constexpr int kLsSlots = kLsItems * kLsWaves;            // ballots of a step
+static_assert(kLsStepSlabs == 4 || kLsStepSlabs == 8, "the list offsets are scanned four slabs (64 lanes x 8 slots) at a time");
 constexpr int kLsMaxEvents8 = 112 * 1024;                // the 8-bit table's limit, as the chunk filter's (kernels_fr.hip kQ8MaxEvents)
 constexpr int kLsMaxEvents4 = 260096;                    // the 4-bit table's (kQ4MaxEvents): two events per byte, levels 0 .. 14, 15 kills
 constexpr int kLsKeyMax = 255;                           // rows of >= 255 entries sort as one class
@@ -321,14 +325,17 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
         zero_bm = e.bm0;
     }
     unsigned long long n_cand = 0;
-    uint32_t nz_prev = 0u; // the items of the previous step this wave found candidates in
+    uint64_t nz_prev = 0u; // the items of the previous step this wave found candidates in
     int it = 0;
     int64_t s_emit = -1;
     for (int64_t s = s_begin;; ++s, ++it) {
         const bool have = s < s_end;
         LsDesc d_nn = ls_load_desc(desc, didx(s + 2), zero_v);
-        if (s_emit >= 0) { // ---- the lists of the previous step's slabs
-            const unsigned long long* mall = s_m + ((it - 1) & 1) * kLsSlots;
+        if (s_emit >= 0) // ---- the lists of the previous step's slabs, four slabs at a time
+#pragma unroll 1
+        for (int h4 = 0; h4 < kLsStepSlabs / 4; ++h4) {
+            const unsigned long long* mall = s_m + ((it - 1) & 1) * kLsSlots + h4 * 512;
+            const int64_t slab0 = s_emit * kLsStepSlabs + h4 * 4;
             // lane l: slots 8 l .. 8 l + 7; a row of 16 lanes = the 128 slots of one slab
             const uint4* q = reinterpret_cast<const uint4*>(mall + 8 * lane);
             const uint4 x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3];
@@ -351,13 +358,13 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
             for (int k = 1; k < 8; ++k) sel = wk == k ? ex[k] : sel;
             const unsigned myoff = inc - run + sel; // list offset of the slot of THIS wave that lane l covers
             if (wave == 0 && (lane & 15) == 15) {
-                const int64_t slab = s_emit * kLsStepSlabs + (lane >> 4);
+                const int64_t slab = slab0 + (lane >> 4);
                 if (slab < n_slabs) cand_cnt[slab] = inc;
             }
 #pragma unroll
-            for (int ls = 0; ls < kLsStepSlabs; ++ls)
-                if (s_emit * kLsStepSlabs + ls < n_slabs) n_cand += (unsigned)__builtin_amdgcn_readlane((int)inc, 16 * ls + 15);
-            uint32_t nz = nz_prev;
+            for (int ls = 0; ls < 4; ++ls)
+                if (slab0 + ls < n_slabs) n_cand += (unsigned)__builtin_amdgcn_readlane((int)inc, 16 * ls + 15);
+            uint32_t nz = (uint32_t)(nz_prev >> (32 * h4));
             while (nz != 0u) { // (wave-uniform)
                 const int jj = __builtin_amdgcn_readfirstlane(__builtin_ctz(nz));
                 nz &= nz - 1u;
@@ -367,11 +374,11 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
                 const unsigned off = (unsigned)__builtin_amdgcn_readlane((int)myoff, jj * 2 + (wave >> 3));
                 if ((m >> lane) & 1ULL) {
                     const unsigned pos = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    cand_list[(s_emit * kLsStepSlabs + (jj >> 3)) * (int64_t)kLsSlabRows + pos] = (uint16_t)((jj & 7) * 1024 + tid);
+                    cand_list[(slab0 + (jj >> 3)) * (int64_t)kLsSlabRows + pos] = (uint16_t)((jj & 7) * 1024 + tid);
                 }
             }
         }
-        uint32_t nz_now = 0u;
+        uint64_t nz_now = 0u;
         if (have) {
             unsigned long long* mw = s_m + (it & 1) * kLsSlots + wave;
             const int n_units = (int)((d_cur.n_rows + kLsUnitRows - 1) / kLsUnitRows);
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
                     if (__builtin_expect((bmv >> t) & 1u, 0)) { /* an item ends here */                                      \
                         const unsigned long long m = __ballot((int)sum <= threshold);                                        \
                         if (lane == 0) mw[jj * kLsWaves] = m;                                                                \
-                        nz_now |= (m != 0ULL ? 1u : 0u) << jj;                                                               \
+                        nz_now |= (uint64_t)(m != 0ULL ? 1u : 0u) << jj;                                                     \
                         sum = 0;                                                                                             \
                         jj = __builtin_amdgcn_readfirstlane(jj + 1);                                                         \
                     }                                                                                                        \
@@ -445,7 +452,9 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
 #endif
         d_cur = d_nxt;
         d_nxt = d_nn;
-        nz_prev = LS_ABL == 4 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)nz_now); // (ablation 4: no list is written)
+        nz_prev = LS_ABL == 4 ? 0ULL // (ablation 4: no list is written)
+                              : ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(nz_now >> 32)) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)nz_now);
         s_emit = have ? s : -1;
         if (!have) break; // nothing left in flight: nobody reads anything of ours any more
         ls_barrier();
