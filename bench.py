@@ -241,8 +241,8 @@ def moved_bytes(variant, info, listed_rows):
                        written and read back;
       every other pass the canonical CSR (algorithmic bytes).
     """
-    if variant == 5 and getattr(info, "stream_bytes_rows", 0):  # the row stream: the exact pass reads a third line per listed row (the permutation)
-        return info.stream_bytes_rows + (listed_rows or 0) * (3 * 128 + 4)
+    if variant == 5 and getattr(info, "stream_bytes_rows", 0):  # the row stream: per listed row the line of its columns and (shared by the item's candidates) the line of its position word
+        return info.stream_bytes_rows + (listed_rows or 0) * (2 * 128 + 4)
     if variant == 5 and info.stream_bytes:
         return info.stream_bytes + (listed_rows or 0) * (2 * 128 + 4)
     if variant == 6 and info.stream_bytes_wide:  # the fixed-point pass streams the 32-bit form of the slab stream
@@ -733,8 +733,8 @@ def main():
                 "canonical_equivalent_gbs": info.algorithmic_bytes / (k_med * 1e-3) / 1e9,
                 "canonical_equivalent_frac": info.algorithmic_bytes / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "achieved / frac = bytes the pass MUST move in the layout it reads (moved_bytes_per_launch: the stream "
-                        "the conservative kernel reads -- stream_bytes_per_launch: the row stream, else the slab stream -- plus three "
-                        "(row stream; else two) 128-B lines and a list entry per row handed to the exact pass, from this run's live count) / MEDIAN kernel time of the "
+                        "the conservative kernel reads -- stream_bytes_per_launch: the row stream, else the slab stream -- plus two "
+                        "128-B lines and a list entry per row handed to the exact pass, from this run's live count) / MEDIAN kernel time of the "
                         "instrumented serial probe / 8 TB/s; traffic / frac_pmc = the PMC-measured HBM bytes of the same workload "
                         "(profiles/traffic*.json, rocprofv3 --pmc passes) over the same time; canonical_equivalent_* = SURVEY 8(d)'s "
                         "32 B-per-cut-set figure of the canonical CSR over the same time: an equivalent rate, not bytes moved (it "

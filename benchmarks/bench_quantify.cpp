@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
         // bytes the pass must move in the layout it reads (bench.py's moved_bytes): the slab stream + two 128-byte lines and a
         // list entry per row handed to the exact pass; the canonical CSR for the other variants
         double moved = (double)info.algorithmic_bytes;
-        if (variant == CANOPY_KERNEL_FILTER_REFINE && info.stream_bytes_rows) moved = (double)info.stream_bytes_rows + (double)listed * 388.0;
+        if (variant == CANOPY_KERNEL_FILTER_REFINE && info.stream_bytes_rows) moved = (double)info.stream_bytes_rows + (double)listed * 260.0;
         else if (variant == CANOPY_KERNEL_FILTER_REFINE && info.stream_bytes) moved = (double)info.stream_bytes + (double)listed * 260.0;
         else if (variant == CANOPY_KERNEL_FIXED_SUM && info.stream_bytes_wide) moved = (double)info.stream_bytes_wide + (double)listed * 260.0;
         else if (info.stream_bytes) moved = (double)info.stream_bytes;

@@ -235,7 +235,9 @@ struct LsOwned { // the quantised filter's row stream (kernels_ls.hip), owned by
     uint32_t* ent = nullptr;   // [n_lines][64] the lanes' bit streams, a range (step, wave) after the other
     uint32_t* bm = nullptr;    // [n_units] item ends of every unit of 32 entry rows
     void* desc = nullptr;      // [n_steps * 16 + 1] ranges: first line, entry rows, first unit
-    uint16_t* perm16 = nullptr;// [n_slabs * 8192] list position -> local row id
+    uint32_t* posinfo = nullptr; // [n_slabs * 8192] list position -> local row id (13 bits) | item length - row length (3 bits; 7 =
+                                 // look the bounds up) | row start relative to its slab's first entry (16 bits)
+    uint8_t* item_len8 = nullptr;// [n_slabs * 128] length of every item, in list order (position >> 6)
     int64_t n_lines = 0, n_units = 0, n_steps = 0, n_slabs = 0;
     int bits = 0;
     int64_t stream_bytes = 0, device_bytes = 0;
@@ -428,12 +430,13 @@ struct FrP24 {
 bool fr_p24_applies(int32_t n_events);
 hipError_t fr_build_pack24(const uint32_t* d_stream32, const int64_t* d_fr_off, int64_t n_slabs, int64_t total_chunks, int32_t n_events,
                            FrP24Owned* p, hipStream_t s);
-// the row stream of the quantised filter (kernels_ls.hip): lists of POSITIONS, translated by perm16 in the exact pass
+// the row stream of the quantised filter (kernels_ls.hip): lists of POSITIONS, translated by posinfo in the exact pass
 struct LsView {
     const uint32_t* ent = nullptr;
     const uint32_t* bm = nullptr;
     const void* desc = nullptr;
-    const uint16_t* perm16 = nullptr;
+    const uint32_t* posinfo = nullptr;
+    const uint8_t* item_len8 = nullptr;
     int64_t n_steps = 0, n_slabs = 0;
     int bits = 0;
 };
@@ -453,7 +456,7 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
 // flagged: the lists come from launch_fx_sum (flag bits 15 / 14 per entry); records go to block_partials[part_offset + block]
 hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, const unsigned* cand_cnt, int slab_rows,
                             int64_t n_slabs, uint64_t* keep_mask, int grid, bool flagged, int part_offset, hipStream_t s,
-                            const uint16_t* perm16 = nullptr);
+                            const uint32_t* posinfo = nullptr, const uint8_t* item_len8 = nullptr);
 int fx_max_row_len();
 int fx_sum_grid(int n_cu, int32_t n_events, int64_t n_slabs);
 void fx_list_units(int32_t n_events, int* unit_rows, int* units_per_slab);

@@ -1195,13 +1195,17 @@ __device__ __forceinline__ double refine_row_sum(const RowKernelArgs& a, int64_t
 // FLAGGED (lists of the fixed-point pass k_fx_sum): bit 15 of an entry = "pass A left this row out: account for it
 // here if it is kept", bit 14 = "argmax contender: its exact s_i takes part in max / argmax"; the filters' lists carry
 // no flags and mean both. Records go to block_partials[part_offset + blockIdx.x].
-// PERM (lists of the row stream, kernels_ls.hip): an entry is a POSITION of its slab, perm16 names the row; the rows of a lane
-// then do not ascend, so an argmax tie is settled here (lower row) and not by arrival.
+// PERM (lists of the row stream, kernels_ls.hip): an entry is a POSITION of its slab; posinfo[position] names the row AND, for
+// nearly every row, its bounds (start relative to the slab's first entry, length = the item's length minus a 3-bit difference):
+// the candidates of an item sit side by side in the list, so they share the 128-byte line of their posinfo words, where the
+// row-bounds lookup costs a random line per candidate. The rows of a lane do not ascend, so an argmax tie is settled here
+// (lower row) and not by arrival.
 template <bool FLAGGED, bool PERM = false>
 __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArgs a, const uint16_t* __restrict__ cand_list,
                                                                    const unsigned* __restrict__ cand_cnt, int slab_rows,
                                                                    int64_t n_slabs, uint64_t* __restrict__ keep_mask,
-                                                                   int part_offset, const uint16_t* __restrict__ perm16 = nullptr) {
+                                                                   int part_offset, const uint32_t* __restrict__ posinfo = nullptr,
+                                                                   const uint8_t* __restrict__ item_len8 = nullptr) {
     __shared__ double s_red[kRefineWaves * kAccDoubles];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -1218,12 +1222,25 @@ __global__ __launch_bounds__(kRefineWaves * kWave) void k_fr_refine(RowKernelArg
         for (int j0 = (int)(u & 1) * kWave; j0 < n; j0 += 2 * kWave) {
             const bool on = j0 + lane < n;
             unsigned entry = on ? (unsigned)cand_list[base + j0 + lane] : 0u;
-            if (PERM) entry = on ? (unsigned)perm16[base + entry] : 0u;
+            uint32_t info = 0u;
+            unsigned pos = entry;
+            if (PERM) {
+                info = on ? posinfo[base + entry] : 0u;
+                entry = info & 8191u;
+            }
             const bool account = !FLAGGED || (entry & 0x8000u) != 0, contend = !FLAGGED || (entry & 0x4000u) != 0;
             const int64_t r = base + (int64_t)(FLAGGED ? (entry & 0x3FFFu) : entry);
             int len = 0;
             int64_t rb = 0;
-            if (on) refine_row_bounds(a, r, &rb, &len);
+            if (on) {
+                const unsigned code = (info >> 13) & 7u;
+                if (PERM && code != 7u) {
+                    len = (int)item_len8[s * 128 + (int64_t)(pos >> 6)] - (int)code;
+                    rb = a.row_ptr[base] + (int64_t)(info >> 16); // (one address for the whole unit)
+                } else {
+                    refine_row_bounds(a, r, &rb, &len);
+                }
+            }
             const double sv = refine_row_sum(a, rb, len, on);
             const bool keep = on && (sv >= a.log_cut) && (a.limit_order == 0 || len <= a.limit_order);
             fold_kept_row(acc.rare, acc.l1p, acc.n_certain, sv, keep && account);
@@ -1775,7 +1792,7 @@ hipError_t fr_build_pack24(const uint32_t* d_stream32, const int64_t* d_fr_off, 
 
 int fr_max_events() { return 1 << 18; }
 bool fr_filter_is_quantised(int32_t n_events) { return fr_use_q8(n_events) && fr_slab_rows_for(n_events) == 8192; }
-int fr_refine_grid(int n_cu) { return n_cu * 8; }
+int fr_refine_grid(int n_cu) { return n_cu * 8; } // (16 per CU: the exact pass 49.3 us against 45.3, the final reduce 10.3 against 7.2)
 
 namespace {
 __global__ void k_fr_off16(const int64_t* __restrict__ row_ptr, int64_t n_rows, uint16_t* __restrict__ off16, int* __restrict__ too_wide) {
@@ -2058,18 +2075,18 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
 
 hipError_t launch_fr_refine(const RowKernelArgs& a, const uint16_t* cand_list, const unsigned* cand_cnt, int slab_rows,
                             int64_t n_slabs, uint64_t* keep_mask, int grid, bool flagged, int part_offset, hipStream_t s,
-                            const uint16_t* perm16) {
-    if (perm16 != nullptr && !flagged) {
+                            const uint32_t* posinfo, const uint8_t* item_len8) {
+    if (posinfo != nullptr && !flagged) {
         hipLaunchKernelGGL((k_fr_refine<false, true>), dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows,
-                           n_slabs, keep_mask, part_offset, perm16);
+                           n_slabs, keep_mask, part_offset, posinfo, item_len8);
         return hipGetLastError();
     }
     if (flagged)
         hipLaunchKernelGGL((k_fr_refine<true, false>), dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows,
-                           n_slabs, keep_mask, part_offset, (const uint16_t*)nullptr);
+                           n_slabs, keep_mask, part_offset, (const uint32_t*)nullptr, (const uint8_t*)nullptr);
     else
         hipLaunchKernelGGL((k_fr_refine<false, false>), dim3(grid), dim3(kRefineWaves * kWave), 0, s, a, cand_list, cand_cnt, slab_rows,
-                           n_slabs, keep_mask, part_offset, (const uint16_t*)nullptr);
+                           n_slabs, keep_mask, part_offset, (const uint32_t*)nullptr, (const uint8_t*)nullptr);
     return hipGetLastError();
 }
 

@@ -19,7 +19,8 @@
 //     every wave turns the step's 512 ballots into list offsets (8 per lane, a 16-lane DPP scan = one list per slab) and
 //     writes the candidates of its own items;
 //   * the lists hold POSITIONS p = j * 1024 + wave * 64 + lane (item j of wave `wave`, row `lane` of the item),
-//     ascending; the exact pass translates them through the slab's permutation perm16[slab * 8192 + p] = local row id.
+//     ascending; the exact pass translates them through posinfo[slab * 8192 + p]: the local row id, and where the row starts
+//     and how long it is (so that it need not look its bounds up).
 // The candidate SET is the one k_fr_filter_q8o lists (same table, same threshold, integer sums); only its order differs.
 #include "canopy_device.h"
 #include "canopy_internal.h"
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void k_ls_desc(const int64_t* __restrict__ lin
 template <int BITS>
 __global__ __launch_bounds__(kLsThreads) void k_ls_fill(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx, int64_t n_rows,
                                                          int32_t n_events, int64_t n_slabs, const LsDesc* __restrict__ desc,
-                                                         uint32_t* __restrict__ ent, uint32_t* __restrict__ bm, uint16_t* __restrict__ perm16) {
+                                                         uint32_t* __restrict__ ent, uint32_t* __restrict__ bm, uint32_t* __restrict__ posinfo,
+                                                         uint8_t* __restrict__ item_len8) {
     __shared__ uint32_t key[kLsSlabRows]; // clamped length << 13 | local row
     __shared__ int s_max;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -175,17 +177,27 @@ __global__ __launch_bounds__(kLsThreads) void k_ls_fill(const int64_t* __restric
                 __syncthreads();
             }
         const int slab_max = s_max;
+        // what the exact pass needs of a listed row, beside its id: where it starts (relative to the slab's first entry: 16 bits, as
+        // off16) and how long it is (its item's length minus a small difference)
+        const int64_t blk_b = row_ptr[slab * kLsSlabRows];
+        const int64_t blk_e = row_ptr[(slab + 1) * kLsSlabRows < n_rows ? (slab + 1) * kLsSlabRows : n_rows];
+        const bool narrow = blk_e - blk_b <= 65535;
         for (int j = 0; j < kLsIPW; ++j) {
             const int item = ls_item_of(j, wave);
             const uint32_t kk = key[item * kWave + lane];
             const uint32_t last = key[item * kWave + kWave - 1] >> 13;
             const int L = last == (uint32_t)kLsKeyMax ? slab_max : (int)last; // (wave-uniform)
             const uint32_t local = kk & 8191u;
-            perm16[slab * kLsSlabRows + j * 1024 + tid] = (uint16_t)local;
             const int64_t r = slab * kLsSlabRows + (int64_t)local;
             const bool real = r < n_rows;
             const int64_t b = real ? row_ptr[r] : 0;
             const int len = real ? (int)(row_ptr[r + 1] - b) : 0;
+            {
+                uint32_t code = 7u, start = 0u; // 7: the exact pass looks the bounds up (off16 / row_ptr)
+                if (real && narrow && L <= 255 && L - len <= 6) { code = (uint32_t)(L - len); start = (uint32_t)(b - blk_b); }
+                posinfo[slab * kLsSlabRows + j * 1024 + tid] = local | (code << 13) | (start << 16);
+                if (lane == 0) item_len8[slab * 128 + j * kLsWaves + wave] = (uint8_t)(L > 255 ? 255 : L);
+            }
             for (int k = 0; k < L; ++k) {
                 uint32_t col = real ? (k < len ? (uint32_t)col_idx[b + k] : pad_col) : kill_col;
                 if (LS_ABL == 2 && real && k < len) { // timing ablation (WRONG results): every lane of a half on a bank of its own
@@ -479,7 +491,8 @@ void ls_free(LsOwned* L) {
     if (L->ent) (void)hipFree(L->ent);
     if (L->bm) (void)hipFree(L->bm);
     if (L->desc) (void)hipFree(L->desc);
-    if (L->perm16) (void)hipFree(L->perm16);
+    if (L->posinfo) (void)hipFree(L->posinfo);
+    if (L->item_len8) (void)hipFree(L->item_len8);
     *L = LsOwned();
 }
 
@@ -541,7 +554,8 @@ hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     e = hipMalloc(&L.ent, (size_t)L.n_lines * 256);
     if (e == hipSuccess) e = hipMalloc(&L.bm, sizeof(uint32_t) * (size_t)L.n_units);
     if (e == hipSuccess) e = hipMalloc(&L.desc, sizeof(LsDesc) * (size_t)(n_ranges + 1));
-    if (e == hipSuccess) e = hipMalloc(&L.perm16, sizeof(uint16_t) * (size_t)(n_slabs * kLsSlabRows));
+    if (e == hipSuccess) e = hipMalloc(&L.posinfo, sizeof(uint32_t) * (size_t)(n_slabs * kLsSlabRows));
+    if (e == hipSuccess) e = hipMalloc(&L.item_len8, (size_t)(n_slabs * 128));
     // (every line of a range is written whole except the bits behind its last entry row; the zero unit must be zero)
     if (e == hipSuccess) e = hipMemsetAsync(L.ent, 0, (size_t)L.n_lines * 256, s);
     if (e == hipSuccess) e = hipMemsetAsync(L.bm, 0, sizeof(uint32_t) * (size_t)L.n_units, s);
@@ -552,7 +566,7 @@ hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     if (e != hipSuccess) return bail(e);
 #define LS_FILL(B)                                                                                                         \
     hipLaunchKernelGGL(k_ls_fill<B>, dim3((unsigned)n_steps), dim3(kLsThreads), 0, s, d_row_ptr, d_col_idx, n_rows, n_events, n_slabs, \
-                       reinterpret_cast<const LsDesc*>(L.desc), L.ent, L.bm, L.perm16)
+                       reinterpret_cast<const LsDesc*>(L.desc), L.ent, L.bm, L.posinfo, L.item_len8)
     switch (bits) {
         case 12: LS_FILL(12); break;
         case 14: LS_FILL(14); break;
@@ -566,7 +580,7 @@ hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     if (e != hipSuccess) return bail(e);
     (void)hipFree(d_sizes); (void)hipFree(d_rows); (void)hipFree(d_lines); (void)hipFree(d_units);
     L.stream_bytes = L.n_lines * 256 + L.n_units * 4 + (n_ranges + 1) * 16;
-    L.device_bytes = L.stream_bytes + n_slabs * kLsSlabRows * 2;
+    L.device_bytes = L.stream_bytes + n_slabs * kLsSlabRows * 4 + n_slabs * 128;
     *out = L;
     *ok = true;
     return hipSuccess;

@@ -545,7 +545,7 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
             LsView lsv;
             use_ls = m->ls_state == 1 && !pl.filter_only && fr_slab_rows(m->n_events) == 8192;
             if (use_ls) {
-                lsv.ent = m->ls.ent; lsv.bm = m->ls.bm; lsv.desc = m->ls.desc; lsv.perm16 = m->ls.perm16;
+                lsv.ent = m->ls.ent; lsv.bm = m->ls.bm; lsv.desc = m->ls.desc; lsv.posinfo = m->ls.posinfo; lsv.item_len8 = m->ls.item_len8;
                 lsv.n_steps = m->ls.n_steps; lsv.n_slabs = m->ls.n_slabs; lsv.bits = m->ls.bits;
             }
             HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, &p24, q8_overlapped, m->max_row_len, m->d_fr_off, m->fr_total_chunks, P->d_logp, P->d_q8, m->n_rows,
@@ -577,7 +577,7 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
         if ((int64_t)grid > g_need) grid = (int)g_need; // a small shard does not pay for 2048 workgroups' records
         HIP_TRY(ctx, launch_fr_refine(a, S.d_fr_list, S.d_fr_cnt, unit_rows, n_units,
                                       pl.want_mask ? ctx->d_keep_mask : nullptr, grid, pl.variant == CANOPY_KERNEL_FIXED_SUM, pl.grid_fx,
-                                      lane, use_ls ? m->ls.perm16 : nullptr));
+                                      lane, use_ls ? m->ls.posinfo : nullptr, use_ls ? m->ls.item_len8 : nullptr));
         n_records = grid + pl.grid_fx;
     } else if (pl.variant == CANOPY_KERNEL_VALUE_SCATTER) {
         HIP_TRY(ctx, launch_vs_kernel(a, m->d_vs_stream, m->d_vs_off, m->d_vs_slab_row, m->vs_total_chunks, m->n_slabs,

@@ -178,8 +178,8 @@ typedef struct canopy_model_info {
     int64_t stream_bytes_rows;  /* bytes the quantised filter of FILTER_REFINE reads when the model has a ROW STREAM (up to 260 096
                                    events: 12 .. 18 bits per entry in length-sorted rows, no row ids; range descriptors, item-end
                                    masks, the logp table once), 0 without one -- a sum-only FILTER_REFINE pass then reads
-                                   stream_bytes. Its lists hold positions: the exact pass reads one more 128-byte line per listed
-                                   row (the slab's permutation) */
+                                   stream_bytes. Its lists hold positions: the exact pass reads a position word per listed row
+                                   (row id, row start, row length: the candidates of an item share its 128-byte line) */
 } canopy_model_info;
 
 CANOPY_API canopy_status canopy_model_get_info(const canopy_model* model, canopy_model_info* info);
