@@ -1,6 +1,6 @@
 """Where does a new probability vector per step cost time? (config 3, one GPU)"""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, canopy_amd
 SEED = 20250704
 ctx = canopy_amd.Context(device=0)

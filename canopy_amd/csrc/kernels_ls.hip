@@ -603,7 +603,8 @@ hipError_t launch_ls_filter(const LsView& L, const uint8_t* q8, int32_t n_events
     const LsDesc* desc = reinterpret_cast<const LsDesc*>(L.desc);
 #define LS_GO(B, N)                                                                                                             \
     do {                                                                                                                        \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fr_filter_ls<B, N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        /* (per device, so at every launch: one process may drive several devices) */                                          \
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fr_filter_ls<B, N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (attr != hipSuccess) return attr;                                                                                    \
         hipLaunchKernelGGL((k_fr_filter_ls<B, N>), dim3((unsigned)g), dim3(kLsThreads), lds, s, L.ent, L.bm, desc, q8, n_events, L.n_steps, L.n_slabs, \
                            threshold, cand_list, cand_cnt, cand_count);                                                         \
