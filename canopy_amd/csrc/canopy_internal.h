@@ -239,7 +239,7 @@ struct LsOwned { // the quantised filter's row stream (kernels_ls.hip), owned by
                                  // look the bounds up) | row start relative to its slab's first entry (16 bits)
     uint8_t* item_len8 = nullptr;// [n_slabs * 128] length of every item, in list order (position >> 6)
     int64_t n_lines = 0, n_units = 0, n_steps = 0, n_slabs = 0;
-    int bits = 0;
+    int bits = 0, ss = 0;      // bits per entry; slabs per step
     int64_t stream_bytes = 0, device_bytes = 0;
 };
 
@@ -438,12 +438,12 @@ struct LsView {
     const uint32_t* posinfo = nullptr;
     const uint8_t* item_len8 = nullptr;
     int64_t n_steps = 0, n_slabs = 0;
-    int bits = 0;
+    int bits = 0, ss = 0;
 };
 bool ls_applies(int32_t n_events);
 void ls_free(LsOwned* L);
-hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int64_t nnz, int32_t n_events, LsOwned* out, bool* ok,
-                    hipStream_t s);
+hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int64_t nnz, int32_t n_events, int n_cu, LsOwned* out,
+                    bool* ok, hipStream_t s);
 hipError_t launch_ls_filter(const LsView& L, const uint8_t* q8, int32_t n_events, bool nib, int threshold, uint16_t* cand_list, unsigned* cand_cnt,
                             unsigned long long* cand_count, int n_cu, hipStream_t s);
 hipError_t launch_fr_q8_table(const double* logp, int32_t n_events, double log_cut, uint8_t* q8_buf, hipStream_t s);

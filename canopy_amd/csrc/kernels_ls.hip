@@ -107,15 +107,15 @@ __global__ __launch_bounds__(256) void k_ls_sizes(const int64_t* __restrict__ ro
 }
 
 // ---- builder 2: lines and units of every range (step, wave) ------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ls_range_sizes(const uint32_t* __restrict__ sizes, int64_t n_slabs, int64_t n_ranges, int bits,
+__global__ __launch_bounds__(256) void k_ls_range_sizes(const uint32_t* __restrict__ sizes, int64_t n_slabs, int64_t n_ranges, int bits, int ss,
                                                         int64_t* __restrict__ lines, int64_t* __restrict__ units, uint32_t* __restrict__ rows) {
     const int64_t rg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (rg >= n_ranges) return;
     const int64_t step = rg / kLsWaves;
     const int w = (int)(rg % kLsWaves);
     uint64_t n = 0;
-    for (int ls = 0; ls < kLsStepSlabs; ++ls) {
-        const int64_t slab = step * kLsStepSlabs + ls;
+    for (int ls = 0; ls < ss; ++ls) {
+        const int64_t slab = step * ss + ls;
         if (slab < n_slabs) n += sizes[slab * kLsWaves + w];
     }
     rows[rg] = (uint32_t)(n > 0xffffffffULL ? 0xffffffffULL : n);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_ls_desc(const int64_t* __restrict__ lin
 // ---- of the 16 ranges and their boundary masks ---------------------------------------------------------------------------
 template <int BITS>
 __global__ __launch_bounds__(kLsThreads) void k_ls_fill(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx, int64_t n_rows,
-                                                         int32_t n_events, int64_t n_slabs, const LsDesc* __restrict__ desc,
+                                                         int32_t n_events, int64_t n_slabs, int ss, const LsDesc* __restrict__ desc,
                                                          uint32_t* __restrict__ ent, uint32_t* __restrict__ bm, uint32_t* __restrict__ posinfo,
                                                          uint8_t* __restrict__ item_len8) {
     __shared__ uint32_t key[kLsSlabRows]; // clamped length << 13 | local row
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(kLsThreads) void k_ls_fill(const int64_t* __restric
     int nb = 0;
     uint32_t dw = 0;
     uint32_t t_row = 0, bm_word = 0; // entry rows written so far; the boundary mask of the unit being written (lane 0)
-    for (int ls = 0; ls < kLsStepSlabs; ++ls) {
-        const int64_t slab = step * kLsStepSlabs + ls;
+    for (int ls = 0; ls < ss; ++ls) {
+        const int64_t slab = step * ss + ls;
         if (slab >= n_slabs) break; // (workgroup-uniform)
         if (tid == 0) s_max = 1;
         __syncthreads();
@@ -283,7 +283,7 @@ __device__ __forceinline__ unsigned ls_row_shr_add(unsigned x) {
 template <int BITS, bool NIB>
 __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __restrict__ ent, const uint32_t* __restrict__ bm,
                                                               const LsDesc* __restrict__ desc, const uint8_t* __restrict__ q8, int32_t n_events,
-                                                              int64_t n_steps, int64_t n_slabs, int threshold, uint16_t* __restrict__ cand_list,
+                                                              int64_t n_steps, int64_t n_slabs, int ss, int threshold, uint16_t* __restrict__ cand_list,
                                                               unsigned* __restrict__ cand_cnt, unsigned long long* __restrict__ cand_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* s_m = reinterpret_cast<unsigned long long*>(smem); // [2][kLsSlots] ballots, slot (ls * 8 + j) * 16 + wave
@@ -347,7 +347,8 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
 #pragma unroll 1
         for (int h4 = 0; h4 < kLsStepSlabs / 4; ++h4) {
             const unsigned long long* mall = s_m + ((it - 1) & 1) * kLsSlots + h4 * 512;
-            const int64_t slab0 = s_emit * kLsStepSlabs + h4 * 4;
+            if (h4 * 4 >= ss) break;
+            const int64_t slab0 = s_emit * ss + h4 * 4;
             // lane l: slots 8 l .. 8 l + 7; a row of 16 lanes = the 128 slots of one slab
             const uint4* q = reinterpret_cast<const uint4*>(mall + 8 * lane);
             const uint4 x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3];
@@ -371,11 +372,11 @@ __global__ __launch_bounds__(kLsThreads) void k_fr_filter_ls(const uint32_t* __r
             const unsigned myoff = inc - run + sel; // list offset of the slot of THIS wave that lane l covers
             if (wave == 0 && (lane & 15) == 15) {
                 const int64_t slab = slab0 + (lane >> 4);
-                if (slab < n_slabs) cand_cnt[slab] = inc;
+                if (h4 * 4 + (lane >> 4) < ss && slab < n_slabs) cand_cnt[slab] = inc;
             }
 #pragma unroll
             for (int ls = 0; ls < 4; ++ls)
-                if (slab0 + ls < n_slabs) n_cand += (unsigned)__builtin_amdgcn_readlane((int)inc, 16 * ls + 15);
+                if (h4 * 4 + ls < ss && slab0 + ls < n_slabs) n_cand += (unsigned)__builtin_amdgcn_readlane((int)inc, 16 * ls + 15);
             uint32_t nz = (uint32_t)(nz_prev >> (32 * h4));
             while (nz != 0u) { // (wave-uniform)
                 const int jj = __builtin_amdgcn_readfirstlane(__builtin_ctz(nz));
@@ -498,13 +499,31 @@ void ls_free(LsOwned* L) {
 
 // Builds the row stream of a model (waits for the stream). *ok = false: the model has no such layout (no rows, too many
 // events, a range too long for its 32-bit counters) -- not an error.
-hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int64_t nnz, int32_t n_events, LsOwned* out, bool* ok,
-                    hipStream_t s) {
+hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int64_t nnz, int32_t n_events, int n_cu, LsOwned* out,
+                    bool* ok, hipStream_t s) {
     *ok = false;
     *out = LsOwned();
     if (!ls_applies(n_events) || n_rows < 1) return hipSuccess;
     const int64_t n_slabs = (n_rows + kLsSlabRows - 1) / kLsSlabRows;
-    const int64_t n_steps = (n_slabs + kLsStepSlabs - 1) / kLsStepSlabs;
+    // Slabs per step (= per workgroup barrier): as many as the filter's buffers hold, unless that leaves most CUs without work -- a
+    // model of 2e6 rows has 245 slabs: 62 steps of four occupy a quarter of the CUs, 245 steps of one nearly all of them. (Not at
+    // the first sign of imbalance: the 1.25e7-row shard of an 8-GPU run has 1526 slabs = 382 steps of four = two rounds on 256 CUs,
+    // the second half empty. 763 steps of two take the pass alone from 53.2 to 49.6 us, but a PIPELINED sequence fills the idle CUs
+    // with the next pass's filter anyway and only pays for the extra barriers: 34.5 against 33.8 us per step.)
+    int ss = kLsStepSlabs;
+    {
+        static const int forced = CANOPY_TUNE_ENV("CANOPY_LS_SS") ? atoi(CANOPY_TUNE_ENV("CANOPY_LS_SS")) : 0; // tuning only
+        const int64_t G = n_cu > 0 ? n_cu : 256;
+        double best = -1.0;
+        for (int c = kLsStepSlabs; c >= 1; c >>= 1) {
+            const int64_t steps = (n_slabs + c - 1) / c, rounds = (steps + G - 1) / G;
+            const double eff = (double)steps / (double)(rounds * G);
+            if (eff >= 0.7) { ss = c; break; }          // the largest step that keeps most CUs busy
+            if (eff > best + 1e-9) { best = eff; ss = c; } // else the best there is (a small model: one slab per step)
+        }
+        if (forced == 1 || forced == 2 || forced == 4 || forced == kLsStepSlabs) ss = forced;
+    }
+    const int64_t n_steps = (n_slabs + ss - 1) / ss;
     const int64_t n_ranges = n_steps * kLsWaves;
     const int bits = ls_bits_for(n_events);
     uint32_t *d_sizes = nullptr, *d_rows = nullptr;
@@ -527,7 +546,7 @@ hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     hipLaunchKernelGGL(k_ls_sizes, dim3((unsigned)n_slabs), dim3(256), 0, s, d_row_ptr, n_rows, n_slabs, d_sizes);
     e = hipGetLastError();
     if (e != hipSuccess) return bail(e);
-    hipLaunchKernelGGL(k_ls_range_sizes, dim3((unsigned)((n_ranges + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_sizes, n_slabs, n_ranges, bits,
+    hipLaunchKernelGGL(k_ls_range_sizes, dim3((unsigned)((n_ranges + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_sizes, n_slabs, n_ranges, bits, ss,
                        d_lines, d_units, d_rows);
     e = hipGetLastError();
     if (e == hipSuccess) e = scan_inclusive_i64(d_lines, n_ranges, s);
@@ -549,6 +568,7 @@ hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     L.n_lines = total_lines + 2 * bits; // (a unit of zero lines behind the stream: what a range's last half and an idle wave request)
     L.n_units = total_units + 1;
     L.n_steps = n_steps;
+    L.ss = ss;
     L.n_slabs = n_slabs;
     L.bits = bits;
     e = hipMalloc(&L.ent, (size_t)L.n_lines * 256);
@@ -565,7 +585,7 @@ hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t 
     e = hipGetLastError();
     if (e != hipSuccess) return bail(e);
 #define LS_FILL(B)                                                                                                         \
-    hipLaunchKernelGGL(k_ls_fill<B>, dim3((unsigned)n_steps), dim3(kLsThreads), 0, s, d_row_ptr, d_col_idx, n_rows, n_events, n_slabs, \
+    hipLaunchKernelGGL(k_ls_fill<B>, dim3((unsigned)n_steps), dim3(kLsThreads), 0, s, d_row_ptr, d_col_idx, n_rows, n_events, n_slabs, ss, \
                        reinterpret_cast<const LsDesc*>(L.desc), L.ent, L.bm, L.posinfo, L.item_len8)
     switch (bits) {
         case 12: LS_FILL(12); break;
@@ -606,7 +626,7 @@ hipError_t launch_ls_filter(const LsView& L, const uint8_t* q8, int32_t n_events
         /* (per device, so at every launch: one process may drive several devices) */                                          \
         const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fr_filter_ls<B, N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (attr != hipSuccess) return attr;                                                                                    \
-        hipLaunchKernelGGL((k_fr_filter_ls<B, N>), dim3((unsigned)g), dim3(kLsThreads), lds, s, L.ent, L.bm, desc, q8, n_events, L.n_steps, L.n_slabs, \
+        hipLaunchKernelGGL((k_fr_filter_ls<B, N>), dim3((unsigned)g), dim3(kLsThreads), lds, s, L.ent, L.bm, desc, q8, n_events, L.n_steps, L.n_slabs, L.ss, \
                            threshold, cand_list, cand_cnt, cand_count);                                                         \
         return hipGetLastError();                                                                                               \
     } while (0)

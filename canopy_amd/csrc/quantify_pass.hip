@@ -117,7 +117,7 @@ canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m) {
     // (optional: the pass runs on the chunks without it)
     if (m->ls_state == 0) {
         bool ls_ok = false;
-        e = ls_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->nnz, m->n_events, &m->ls, &ls_ok, ctx->stream);
+        e = ls_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->nnz, m->n_events, ctx->n_cu, &m->ls, &ls_ok, ctx->stream);
         if (e != hipSuccess) { (void)hipGetLastError(); ls_ok = false; }
         m->ls_state = ls_ok ? 1 : -1;
         if (ls_ok) m->device_bytes += m->ls.device_bytes;
@@ -546,7 +546,7 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
             use_ls = m->ls_state == 1 && !pl.filter_only && fr_slab_rows(m->n_events) == 8192;
             if (use_ls) {
                 lsv.ent = m->ls.ent; lsv.bm = m->ls.bm; lsv.desc = m->ls.desc; lsv.posinfo = m->ls.posinfo; lsv.item_len8 = m->ls.item_len8;
-                lsv.n_steps = m->ls.n_steps; lsv.n_slabs = m->ls.n_slabs; lsv.bits = m->ls.bits;
+                lsv.n_steps = m->ls.n_steps; lsv.n_slabs = m->ls.n_slabs; lsv.bits = m->ls.bits; lsv.ss = m->ls.ss;
             }
             HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, &p24, q8_overlapped, m->max_row_len, m->d_fr_off, m->fr_total_chunks, P->d_logp, P->d_q8, m->n_rows,
                                              m->n_events, m->n_fr_slabs, a.log_cut, S.d_fr_list, S.d_fr_cnt, S.d_fr_count,
