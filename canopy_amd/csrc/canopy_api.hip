@@ -490,7 +490,7 @@ canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, int32_t ker
     if (m->device != ctx->device) return fail(ctx, CANOPY_ERR_INVALID_ARGUMENT, "model lives on another device");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int variant = kernel == CANOPY_KERNEL_AUTO ? auto_variant(m) : kernel;
-    if (kernel == CANOPY_KERNEL_AUTO && m->n_events >= 1 && m->n_events <= fr_max_events() && m->n_rows >= fr_min_rows(variant)) {
+    if (kernel == CANOPY_KERNEL_AUTO && m->n_events >= 1 && m->n_events <= fr_max_events() && m->n_rows >= fr_min_rows(variant, true)) {
         canopy_status fst = build_fr(ctx, m); // AUTO picks filter/refine for cut_off > 0
         if (fst != CANOPY_OK) return fst;
         // the stream of the exact all-rows kernel (cut_off = 0, per-row output, > 20 % survivors) is built by the

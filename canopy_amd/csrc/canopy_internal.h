@@ -359,7 +359,7 @@ canopy_status build_vs(canopy_ctx* ctx, const canopy_model* m);
 canopy_status build_ws(canopy_ctx* ctx, const canopy_model* m);
 canopy_status build_bs(canopy_ctx* ctx, const canopy_model* m, bool explicit_request);
 int auto_variant(const canopy_model* m);
-int64_t fr_min_rows(int base_variant);
+int64_t fr_min_rows(int base_variant, bool sequence);
 canopy_status fail(canopy_ctx* ctx, canopy_status st, const std::string& msg);
 uint64_t next_object_id();
 

@@ -67,7 +67,13 @@ int auto_variant(const canopy_model* m) {
 // Sizes from which the two slab passes replace the row kernel AUTO would run (round 2, pipelined and serial passes at
 // E = 1e3 and 1e5: filter/refine is level with the row kernels at ~4e5 .. 7e5 rows serially and ahead from 1e5 rows in a
 // pipelined sequence; the fixed-point pass is level with ROWS_LDS at ~3e6 rows, with ROWS / WAVE_STREAM at ~1e6)
-int64_t fr_min_rows(int base_variant) { return base_variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)1000000 : (int64_t)500000; }
+// (end of round 3, with the row stream and one slab per step on small models, benchmarks/crossover.py: a pass alone -- three short
+// kernels, 37-39 us whatever the size -- is level with ROWS at ~3.5e5 rows (E = 1e5) and with ROWS_LDS at ~5.5e5 (E = 1e3); in a
+// pipelined sequence of passes it is ahead from the smallest sizes measured: 13-17 us per step against 21-22 at 5e4 .. 2e5 rows)
+int64_t fr_min_rows(int base_variant, bool sequence) {
+    if (sequence) return (int64_t)100000;
+    return base_variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)600000 : (int64_t)400000;
+}
 static int64_t fx_min_rows(int base_variant) { return base_variant == CANOPY_KERNEL_ROWS_LDS ? (int64_t)4000000 : (int64_t)1000000; }
 
 // ---- lazy derived layouts (one-off per model, independent of p; every build runs under m->mu and ends with a host
@@ -271,8 +277,10 @@ canopy_status plan_pass(canopy_ctx* ctx, const canopy_model* m, const PSet* P, c
                                   !(ctx->fx_known_id == m->id && ctx->fx_known_fraction > 0.2 &&
                                     ctx->fx_known_cut_off == params->cut_off && ctx->fx_known_version == P->version);
     const double fr_leave_at = fx_can_take_over ? 0.15 : 0.2;
+    // (an asynchronous sum-only pass on a pipelining context is taken to be one of a sequence: the synchronous canopy_quantify is not)
+    const bool sequence = ctx->pipeline_on && !ctx->want_last_timing && !pl.want_mask && !pl.want_imp && !ctx->capturing;
     if (params->kernel == CANOPY_KERNEL_AUTO && params->cut_off > 0.0 && !pl.want_rows &&
-        m->n_events >= 1 && m->n_events <= fr_max_events() && m->n_rows >= fr_min_rows(variant) &&
+        m->n_events >= 1 && m->n_events <= fr_max_events() && m->n_rows >= fr_min_rows(variant, sequence) &&
         !(ctx->fr_known_id == m->id && ctx->fr_known_fraction > fr_leave_at && ctx->fr_known_cut_off == params->cut_off &&
           ctx->fr_known_version == P->version)) {
         canopy_status pst = build_fr(ctx, m);
