@@ -534,7 +534,7 @@ def main():
     if variant == 5 and getattr(info, "stream_bytes_rows", 0):
         kernel_label = ("k_fr_filter_ls + k_fr_refine (quantised conservative filter over the ROW STREAM -- rows sorted by length inside every "
                         "8192-row slab, one row per lane, 12 .. 18-bit columns, no row ids; lists of positions -- then exact refine of the "
-                        "listed rows through the slab's permutation)")
+                        "listed rows through their position words: row id, row start, row length)")
 
     info = model.info()  # (before the all-rows leg adds its own layout to device_bytes)
     k_mean, k_med, k_min = stats([a for a, _ in launches])

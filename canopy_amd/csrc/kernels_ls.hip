@@ -8,12 +8,13 @@
 //     length L is L "entry rows": the lane's k-th column, k < L (rows shorter than their item are padded with a column
 //     whose table value is 0, the rows past the model's end carry a column whose value kills them) -- no row ids in the
 //     stream at all;
-//   * a lane's columns are a bit stream of BITS = 17 (16 up to 65534 events) bits per entry -- 12 / 14 / 16 / 17 / 18 by the number of events --; 32 entry rows = BITS dwords
-//     per lane = one UNIT of BITS 256-byte lines: 2.125 bytes per entry instead of 3.03;
+//   * a lane's columns are a bit stream of BITS bits per entry -- 12 / 14 / 16 / 17 / 18 by the number of events (17 at config 3;
+//     beyond 112 K events the table is the 4-bit one) --; 32 entry rows = BITS dwords per lane = one UNIT of BITS 256-byte lines:
+//     2.125 bytes per entry instead of 3.03;
 //   * the sorted items of a slab go to the 16 waves in a serpentine (every wave gets the same share of every length class:
-//     ls_item_of); the 8 items a wave has in each
-//     of the kLsStepSlabs consecutive slabs of a STEP are contiguous: a wave streams one RANGE per step, in units, one
-//     workgroup barrier per step;
+//     ls_item_of); the 8 items a wave has in each of the consecutive slabs of a STEP (four; two or one in a model so small that
+//     steps of four would leave most CUs idle) are contiguous: a wave streams one RANGE per step, in units, one workgroup
+//     barrier per step;
 //   * per entry: one bit-field extract -> one ds_read_u8 of the 8-bit table in LDS -> a register add. No LDS atomics, no
 //     row sums in LDS. A bit mask per unit says where items end: there one ballot goes to LDS. After the step's barrier
 //     every wave turns the step's 512 ballots into list offsets (8 per lane, a 16-lane DPP scan = one list per slab) and
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void k_ls_desc(const int64_t* __restrict__ lin
     desc[rg] = d;
 }
 
-// ---- builder 3: one workgroup per step: sort every slab's rows by (length, row), write the permutation, the bit streams
+// ---- builder 3: one workgroup per step: sort every slab's rows by (length, row), write the position words (row id, start, length), the bit streams
 // ---- of the 16 ranges and their boundary masks ---------------------------------------------------------------------------
 template <int BITS>
 __global__ __launch_bounds__(kLsThreads) void k_ls_fill(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx, int64_t n_rows,
