@@ -439,13 +439,14 @@ struct LsView {
     const uint8_t* item_len8 = nullptr;
     int64_t n_steps = 0, n_slabs = 0;
     int bits = 0, ss = 0;
+    bool alone = false; // the pass is not one of a pipelined sequence: the filter reads its stream with non-temporal loads
 };
 bool ls_applies(int32_t n_events);
 void ls_free(LsOwned* L);
 hipError_t ls_build(const int64_t* d_row_ptr, const int32_t* d_col_idx, int64_t n_rows, int64_t nnz, int32_t n_events, int n_cu, LsOwned* out,
                     bool* ok, hipStream_t s);
-hipError_t launch_ls_filter(const LsView& L, const uint8_t* q8, int32_t n_events, bool nib, int threshold, uint16_t* cand_list, unsigned* cand_cnt,
-                            unsigned long long* cand_count, int n_cu, hipStream_t s);
+hipError_t launch_ls_filter(const LsView& L, const uint8_t* q8, int32_t n_events, bool nib, bool alone, int threshold, uint16_t* cand_list,
+                            unsigned* cand_cnt, unsigned long long* cand_count, int n_cu, hipStream_t s);
 hipError_t launch_fr_q8_table(const double* logp, int32_t n_events, double log_cut, uint8_t* q8_buf, hipStream_t s);
 bool fr_q8_overlapped(const FrP24* p24, int32_t n_events, int32_t max_row_len);
 void fr_q8_overlapped_units(int* unit_rows, int* units_per_slab);

@@ -1963,7 +1963,7 @@ hipError_t launch_fr_filter_q8(const uint32_t* stream, const FrP24* p24, bool ov
         if (e != hipSuccess) return e;
     }
     if (ls != nullptr) // the row stream (kernels_ls.hip): the same table and threshold, lists of positions
-        return launch_ls_filter(*ls, q8_buf, n_events, nib, threshold, cand_list, cand_cnt, cand_count, n_cu, s);
+        return launch_ls_filter(*ls, q8_buf, n_events, nib, ls->alone, threshold, cand_list, cand_cnt, cand_count, n_cu, s);
     static const int u = CANOPY_TUNE_ENV("CANOPY_FR_QU") ? atoi(CANOPY_TUNE_ENV("CANOPY_FR_QU")) : 4; // tuning only (chunks in flight per wave)
     static const int fr_dbg = CANOPY_TUNE_ENV("CANOPY_FR_DEBUG") ? atoi(CANOPY_TUNE_ENV("CANOPY_FR_DEBUG")) : 0; // timing ablations only
     const int H = fr_parts_for(n_events);

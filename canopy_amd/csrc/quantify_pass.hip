@@ -555,6 +555,7 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
             if (use_ls) {
                 lsv.ent = m->ls.ent; lsv.bm = m->ls.bm; lsv.desc = m->ls.desc; lsv.posinfo = m->ls.posinfo; lsv.item_len8 = m->ls.item_len8;
                 lsv.n_steps = m->ls.n_steps; lsv.n_slabs = m->ls.n_slabs; lsv.bits = m->ls.bits; lsv.ss = m->ls.ss;
+                lsv.alone = !pl.pipelined || ctx->want_last_timing; // (the synchronous canopy_quantify is a pass alone too)
             }
             HIP_TRY(ctx, launch_fr_filter_q8(m->d_fr_stream, &p24, q8_overlapped, m->max_row_len, m->d_fr_off, m->fr_total_chunks, P->d_logp, P->d_q8, m->n_rows,
                                              m->n_events, m->n_fr_slabs, a.log_cut, S.d_fr_list, S.d_fr_cnt, S.d_fr_count,
