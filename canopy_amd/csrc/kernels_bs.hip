@@ -281,6 +281,22 @@ __device__ __forceinline__ void bs_epilogue(double* sums, double* pend, int& n_p
     if (wave == 0) sums[kBsSlabRows + lane] = 0.0; // the sinks
 }
 
+// The stream is read with NON-TEMPORAL loads: its lines then do not push the logp table (which the gathers read through L1 / L2)
+// out of the caches: 0.866 -> 0.839 ms at config 3 with every s_i written (-DBS_NT=0: ordinary loads). The passes this kernel serves
+// run one at a time (per-row outputs are not pipelined), which is where such loads pay: in k_fr_filter_ls they cost 4 % when two
+// passes share the memory system, and in k_fx2 (whose passes are pipelined) they bought nothing, 0.7135 against 0.709 ms.
+#ifndef BS_NT
+#define BS_NT 1
+#endif
+__device__ __forceinline__ uint4 BS_LOAD(const uint4* p) {
+#if BS_NT
+    typedef uint32_t bs_u32x4 __attribute__((ext_vector_type(4)));
+    const bs_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const bs_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
 template <bool ROWS, bool MASK>
 __global__ __launch_bounds__(kBsThreads) __attribute__((amdgpu_waves_per_eu(kBsWaves * BS_WGS / 4))) void k_bs(const uint4* __restrict__ stream, const int64_t* __restrict__ ss_off,
                                                    const int32_t* __restrict__ ss_used, const double* __restrict__ logp,
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(kBsThreads) __attribute__((amdgpu_waves_per_eu(kBsW
             if (ls < s_end) { lp = bs_uload(ss_off + ls); lp_end = lp + __builtin_amdgcn_readfirstlane(ss_used[ls]); } \
             else { lp = sc.total_ss; lp_end = sc.total_ss + 1; break; }                                     \
         }                                                                                                  \
-        Q = stream[(lp * kBsWaves + wave) * kWave + lane];                                                 \
+        Q = BS_LOAD(&stream[(lp * kBsWaves + wave) * kWave + lane]);                                       \
         if (ls < s_end) ++lp;                                                                              \
     }
     int64_t s = s_begin;
