@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=${OUT:-/tmp/asan_build}; mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden -DCANOPY_BUILD -DCANOPY_SHARED -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer -I$R/include -I$R/canopy_amd/csrc"
 pids=""
-for f in canopy_api.hip quantify_pass.hip host_pool.cpp kernels_rows.hip kernels_build.hip kernels_ws.hip kernels_bs.hip kernels_vs.hip kernels_mc.hip kernels_fr.hip kernels_batch.hip comm_rccl.hip mef_lowering.cpp; do
+for f in canopy_api.hip quantify_pass.hip host_pool.cpp kernels_rows.hip kernels_build.hip kernels_ws.hip kernels_bs.hip kernels_ls.hip kernels_vs.hip kernels_mc.hip kernels_fr.hip kernels_batch.hip comm_rccl.hip mef_lowering.cpp; do
   /opt/rocm/bin/hipcc $FLAGS -c $R/canopy_amd/csrc/$f -o $OUT/$f.o &
   pids="$pids $!"
 done
