@@ -57,7 +57,7 @@ void free_model_buffers(canopy_model* m) {
     if (m->d_vs_slab_row) (void)hipFree(m->d_vs_slab_row);
     if (m->d_fr_stream) (void)hipFree(m->d_fr_stream);
     if (m->d_fr_off) (void)hipFree(m->d_fr_off);
-    m->d_fr_stream = nullptr; m->d_fr_off = nullptr; m->fr_state = 0;
+    m->d_fr_stream = nullptr; m->d_fr_off = nullptr; m->fr_state = 0; m->fr_chunks = 0;
     if (m->fr24.stream) (void)hipFree(m->fr24.stream);
     if (m->fr24.base) (void)hipFree(m->fr24.base);
     if (m->fr24.exc) (void)hipFree(m->fr24.exc);
@@ -381,9 +381,9 @@ canopy_status canopy_model_get_info(const canopy_model* m, canopy_model_info* in
     info->device_bytes = m->device_bytes;
     info->stream_bytes = 0;
     info->stream_bytes_wide = 0;
-    if (m->fr_state == 1)
+    if (m->fr_state == 1 && m->fr_chunks == 1)
         info->stream_bytes_wide = m->fr_total_chunks * 1024 + (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8 + (int64_t)m->n_events * 8;
-    if (m->fr_state == 1) // what the quantised filter streams: the 24-bit form when the model has one
+    if (m->fr_state == 1 && m->fr_chunks == 1) // the chunks in the form the quantised filter reads: 24-bit when the model has one
         info->stream_bytes = m->fr_total_chunks * (m->fr24.stream ? 768 + 4 : 1024) + (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8 +
                              m->n_fr_slabs * 8 + (int64_t)m->n_events * 8;
     else if (m->vs_state == 1)
@@ -504,7 +504,11 @@ canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* m, int32_t ker
         if (m->fr_state != 1) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a filter/refine stream");
         if (variant == CANOPY_KERNEL_FIXED_SUM && m->max_row_len > fx_max_row_len())
             return fail(ctx, CANOPY_ERR_UNSUPPORTED, "FIXED_SUM needs rows of at most 63 entries");
-        if (variant == CANOPY_KERNEL_FIXED_SUM) return ensure_fr32(ctx, m); // (the filter reads the 24-bit form when there is one)
+        if (variant == CANOPY_KERNEL_FIXED_SUM) { // (the filter reads the row stream, or the 24-bit form when there is one)
+            st = ensure_fr_chunks(ctx, m);
+            if (st != CANOPY_OK) return st;
+            return ensure_fr32(ctx, m);
+        }
         return CANOPY_OK;
     }
     if (variant == CANOPY_KERNEL_VALUE_SCATTER) {

@@ -292,6 +292,8 @@ struct canopy_model {
     mutable FrP24Owned fr24; // 24-bit form of the same chunks (quantised filter), or nulls
     mutable uint16_t* d_off16 = nullptr; // [n_rows + 1] row start minus the start of the row's 8192-row block (null: some block holds > 65535 entries)
     mutable int fr_state = 0;
+    mutable int fr_chunks = 0; // 1: the chunk stream (d_fr_stream and / or fr24) exists; 0 with fr_state 1: the row stream serves the
+                               // filter, the chunks are built by the first pass that reads them (ensure_fr_chunks)
     mutable LsOwned ls;       // the row stream of the quantised filter (E <= 112 K), built with the slab stream
     mutable int ls_state = 0; // 0 not built, 1 ready, -1 the model has none
 };
@@ -355,6 +357,7 @@ void apply_feedback(canopy_ctx* ctx, canopy_ctx::PassScratch& S, unsigned long l
 // lazy derived layouts (under m->mu)
 canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m);
 canopy_status ensure_fr32(canopy_ctx* ctx, const canopy_model* m);
+canopy_status ensure_fr_chunks(canopy_ctx* ctx, const canopy_model* m);
 canopy_status build_vs(canopy_ctx* ctx, const canopy_model* m);
 canopy_status build_ws(canopy_ctx* ctx, const canopy_model* m);
 canopy_status build_bs(canopy_ctx* ctx, const canopy_model* m, bool explicit_request);

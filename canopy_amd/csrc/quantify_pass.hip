@@ -79,17 +79,13 @@ static int64_t fx_min_rows(int base_variant) { return base_variant == CANOPY_KER
 // ---- lazy derived layouts (one-off per model, independent of p; every build runs under m->mu and ends with a host
 // ---- wait, so that ANY stream of any context may read the layout afterwards) -------------------------------------
 
-canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m) {
-    std::lock_guard<std::mutex> lk(m->mu);
-    if (m->fr_state != 0) return CANOPY_OK;
-    bool ok = false;
-    HIP_TRY(ctx, fr_offsets(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, &m->d_fr_off, &m->fr_total_chunks, &m->n_fr_slabs, &ok, ctx->stream));
-    if (!ok) { m->fr_state = -1; return CANOPY_OK; }
-    auto drop = [&](hipError_t e, const char* what) { // a failed build leaves no half-made layout behind
+// the column-sorted chunks of a model whose offsets are known (m->mu held): the 32-bit stream, its 24-bit form where the model
+// allows one (the 32-bit form then goes again: ensure_fr32 brings it back for the passes that read it)
+static canopy_status build_fr_chunks_locked(canopy_ctx* ctx, const canopy_model* m) {
+    auto drop = [&](hipError_t e, const char* what) { // a failed build leaves no half-made stream behind (the offsets stay)
         (void)hipGetLastError();
-        if (m->d_fr_off) (void)hipFree(m->d_fr_off);
         if (m->d_fr_stream) (void)hipFree(m->d_fr_stream);
-        m->d_fr_off = nullptr; m->d_fr_stream = nullptr; m->fr_total_chunks = 0; m->n_fr_slabs = 0;
+        m->d_fr_stream = nullptr;
         return fail(ctx, e == hipErrorOutOfMemory ? CANOPY_ERR_OUT_OF_MEMORY : CANOPY_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
     };
     hipError_t e = fr_build_sorted32(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, m->d_fr_off, m->fr_total_chunks,
@@ -104,10 +100,7 @@ canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m) {
         m->fr24 = FrP24Owned();
         return drop(e, "fr_build_pack24");
     }
-    m->device_bytes += (m->fr_total_chunks + 1) * 1024 + (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8;
-    e = fr_build_off16(m->d_row_ptr, m->n_rows, &m->d_off16, ctx->stream); // 2 B per row: what the exact pass reads instead of row_ptr
-    if (e != hipSuccess) { (void)hipGetLastError(); m->d_off16 = nullptr; }  // (optional layout: the pass runs without it)
-    if (m->d_off16) m->device_bytes += (m->n_rows + 1) * 2;
+    m->device_bytes += (m->fr_total_chunks + 1) * 1024;
     if (m->fr24.stream) {
         m->device_bytes += (m->fr_total_chunks + 1) * (768 + 4) + (m->n_fr_slabs + 1) * 4;
         // the quantised filter reads the 24-bit form only: the 32-bit stream goes, and comes back (ensure_fr32, ~15 ms at
@@ -119,8 +112,24 @@ canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m) {
             m->device_bytes -= (m->fr_total_chunks + 1) * 1024;
         }
     }
-    // the row stream of the quantised filter (kernels_ls.hip): what a sum-only pass at E <= 112 K reads instead of the chunks
-    // (optional: the pass runs on the chunks without it)
+    m->fr_chunks = 1;
+    return CANOPY_OK;
+}
+
+// What the two slab passes read. The chunk offsets, the exact pass's 2-byte row offsets and -- up to 260 096 events -- the
+// quantised filter's row stream (kernels_ls.hip) are built here; the column-sorted CHUNKS themselves (14 ms and 1.8 GB at
+// config 3) only for a model without a row stream: a sum-only FILTER_REFINE pass never reads them, and the passes that do
+// (FIXED_SUM, the batch path, which walks the lists itself) build them when they first run (ensure_fr_chunks).
+canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (m->fr_state != 0) return CANOPY_OK;
+    bool ok = false;
+    HIP_TRY(ctx, fr_offsets(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, &m->d_fr_off, &m->fr_total_chunks, &m->n_fr_slabs, &ok, ctx->stream));
+    if (!ok) { m->fr_state = -1; return CANOPY_OK; }
+    m->device_bytes += (m->n_fr_slabs * fr_parts(m->n_events) + 1) * 8;
+    hipError_t e = fr_build_off16(m->d_row_ptr, m->n_rows, &m->d_off16, ctx->stream); // 2 B per row: what the exact pass reads instead of row_ptr
+    if (e != hipSuccess) { (void)hipGetLastError(); m->d_off16 = nullptr; }  // (optional layout: the pass runs without it)
+    if (m->d_off16) m->device_bytes += (m->n_rows + 1) * 2;
     if (m->ls_state == 0) {
         bool ls_ok = false;
         e = ls_build(m->d_row_ptr, m->d_col_idx, m->n_rows, m->nnz, m->n_events, ctx->n_cu, &m->ls, &ls_ok, ctx->stream);
@@ -128,14 +137,33 @@ canopy_status build_fr(canopy_ctx* ctx, const canopy_model* m) {
         m->ls_state = ls_ok ? 1 : -1;
         if (ls_ok) m->device_bytes += m->ls.device_bytes;
     }
+    static const bool eager = CANOPY_TUNE_ENV("CANOPY_FR_EAGER_CHUNKS") != nullptr; // tuning only
+    if (m->ls_state != 1 || eager) {
+        canopy_status st = build_fr_chunks_locked(ctx, m);
+        if (st != CANOPY_OK) { // nothing half-made stays behind
+            if (m->d_fr_off) (void)hipFree(m->d_fr_off);
+            m->d_fr_off = nullptr; m->fr_total_chunks = 0; m->n_fr_slabs = 0;
+            if (m->d_off16) { (void)hipFree(m->d_off16); m->d_off16 = nullptr; }
+            ls_free(&m->ls);
+            m->ls_state = 0;
+            return st;
+        }
+    }
     m->fr_state = 1;
     return CANOPY_OK;
+}
+
+// the chunks of a model whose build_fr left them to the first pass that reads them
+canopy_status ensure_fr_chunks(canopy_ctx* ctx, const canopy_model* m) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (m->fr_state != 1 || m->fr_chunks == 1) return CANOPY_OK;
+    return build_fr_chunks_locked(ctx, m);
 }
 
 // the 32-bit slab stream of a model whose build_fr gave it up for the 24-bit form
 canopy_status ensure_fr32(canopy_ctx* ctx, const canopy_model* m) {
     std::lock_guard<std::mutex> lk(m->mu);
-    if (m->fr_state != 1 || m->d_fr_stream != nullptr) return CANOPY_OK;
+    if (m->fr_state != 1 || m->fr_chunks != 1 || m->d_fr_stream != nullptr) return CANOPY_OK;
     HIP_TRY(ctx, fr_build_sorted32(m->d_row_ptr, m->d_col_idx, m->n_rows, m->n_events, m->d_fr_off, m->fr_total_chunks,
                                    m->n_fr_slabs, &m->d_fr_stream, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -324,12 +352,22 @@ canopy_status ensure_layouts(canopy_ctx* ctx, const canopy_model* m, const canop
         canopy_status pst = build_fr(ctx, m);
         if (pst != CANOPY_OK) return pst;
         if (m->fr_state != 1) return fail(ctx, CANOPY_ERR_UNSUPPORTED, "model cannot be laid out as a filter/refine stream");
-        // the 32-bit form of the stream, if this pass reads it and the model gave it up for the 24-bit one
-        const bool reads_p24 = pl.variant == CANOPY_KERNEL_FILTER_REFINE && fr_filter_is_quantised(m->n_events) && m->fr24.stream != nullptr;
-        if (!reads_p24 && m->d_fr_stream == nullptr) {
-            if (ctx->capturing) return fail(ctx, CANOPY_ERR_STATE, "the slab stream must exist before a capture");
-            pst = ensure_fr32(ctx, m);
-            if (pst != CANOPY_OK) return pst;
+        // the row stream serves the quantised filter of a pass that does not hand its lists out: no chunk is read
+        const bool ls_serves = pl.variant == CANOPY_KERNEL_FILTER_REFINE && m->ls_state == 1 && !pl.filter_only &&
+                               fr_filter_is_quantised(m->n_events) && fr_slab_rows(m->n_events) == 8192;
+        if (!ls_serves) {
+            if (m->fr_chunks != 1) {
+                if (ctx->capturing) return fail(ctx, CANOPY_ERR_STATE, "the slab stream must exist before a capture");
+                pst = ensure_fr_chunks(ctx, m);
+                if (pst != CANOPY_OK) return pst;
+            }
+            // the 32-bit form of the stream, if this pass reads it and the model gave it up for the 24-bit one
+            const bool reads_p24 = pl.variant == CANOPY_KERNEL_FILTER_REFINE && fr_filter_is_quantised(m->n_events) && m->fr24.stream != nullptr;
+            if (!reads_p24 && m->d_fr_stream == nullptr) {
+                if (ctx->capturing) return fail(ctx, CANOPY_ERR_STATE, "the slab stream must exist before a capture");
+                pst = ensure_fr32(ctx, m);
+                if (pst != CANOPY_OK) return pst;
+            }
         }
     }
     if (pl.variant == CANOPY_KERNEL_VALUE_SCATTER) {
@@ -551,7 +589,7 @@ canopy_status launch_pass(canopy_ctx* ctx, const canopy_model* m, PSet* P, int s
             // the row stream when the model has one (its lists hold positions: the batch path, which reads the lists itself,
             // stays on the chunks)
             LsView lsv;
-            use_ls = m->ls_state == 1 && !pl.filter_only && fr_slab_rows(m->n_events) == 8192;
+            use_ls = m->ls_state == 1 && !pl.filter_only && fr_slab_rows(m->n_events) == 8192; // (= ensure_layouts' ls_serves)
             if (use_ls) {
                 lsv.ent = m->ls.ent; lsv.bm = m->ls.bm; lsv.desc = m->ls.desc; lsv.posinfo = m->ls.posinfo; lsv.item_len8 = m->ls.item_len8;
                 lsv.n_steps = m->ls.n_steps; lsv.n_slabs = m->ls.n_slabs; lsv.bits = m->ls.bits; lsv.ss = m->ls.ss;

@@ -89,7 +89,10 @@ def test_24_bit_stream_exception_slab_and_rebuild(gpu_ctx, oracle):
     model.set_probabilities(p)
     model.prepare(_capi.KERNEL_FILTER_REFINE)
     nnz = int(row_ptr[-1])
-    assert model.info().stream_bytes < 3.3 * nnz + 8 * n_events + 4096  # 3 B per entry (+ table, offsets), not 4
+    # a model with a row stream leaves the column-sorted chunks to the first pass that reads them
+    assert model.info().stream_bytes == 0 and model.info().stream_bytes_rows > 0
+    model.prepare(_capi.KERNEL_FIXED_SUM)
+    assert 0 < model.info().stream_bytes < 3.3 * nnz + 8 * n_events + 4096  # 3 B per entry (+ table, offsets), not 4
     for cut_off in (1e-8, 1e-5):
         want = oracle.quantify(row_ptr, col, p, cut_off=cut_off, limit_order=20, n_threads=4, want_rows=False)
         for kern in (_capi.KERNEL_FILTER_REFINE, _capi.KERNEL_FIXED_SUM, _capi.KERNEL_FILTER_REFINE):
@@ -104,7 +107,7 @@ def test_24_bit_stream_exception_slab_and_rebuild(gpu_ctx, oracle):
     p = oracle.synth_probabilities(20250704, n_events)
     model = gpu_ctx.upload(row_ptr, col, n_events)
     model.set_probabilities(p)
-    model.prepare(_capi.KERNEL_FILTER_REFINE)
+    model.prepare(_capi.KERNEL_FIXED_SUM)  # (builds the chunks: the filter itself would read the row stream)
     assert model.info().stream_bytes >= 4 * int(row_ptr[-1])
     want = oracle.quantify(row_ptr, col, p, cut_off=1e-3, limit_order=20, n_threads=4, want_rows=False)
     got = gpu_ctx.quantify(model, default_params(cut_off=1e-3, kernel=_capi.KERNEL_FILTER_REFINE))
