@@ -209,10 +209,13 @@ CANOPY_API canopy_status canopy_model_set_log_probabilities(canopy_ctx* ctx, can
                                                             const double* logp);
 
 /*
- * Build the derived device layout a kernel variant needs (today: the wave-slab stream of
- * CANOPY_KERNEL_WAVE_STREAM; a no-op for the others). One-off per model, independent of p.
+ * Build the derived device layout a kernel variant needs: the wave-slab stream (WAVE_STREAM), the band stream (BAND_STREAM),
+ * the value-scatter stream (VALUE_SCATTER), for the two slab passes the chunk offsets, the exact pass's row offsets and -- up
+ * to 260 096 events -- the quantised filter's ROW STREAM (FILTER_REFINE; FIXED_SUM also builds the column-sorted chunks it
+ * reads, which a model with a row stream otherwise leaves to the first pass that needs them); a no-op for the row kernels.
+ * One-off per model, independent of p.
  * kernel = CANOPY_KERNEL_AUTO prepares what AUTO will pick. canopy_quantify_async prepares lazily
- * (and synchronously) when this was not called. Returns CANOPY_ERR_UNSUPPORTED if the variant was
+ * (and synchronously) when this was not called; a pass that is being CAPTURED cannot: prepare its variant first. Returns CANOPY_ERR_UNSUPPORTED if the variant was
  * asked for explicitly and the model cannot be represented in it (E >= 2^19 or absurd row lengths).
  */
 CANOPY_API canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* model, int32_t kernel);
@@ -249,8 +252,9 @@ enum {
     CANOPY_KERNEL_VALUE_SCATTER = 4, /* derived layout: per-slab column-ordered entry stream, gathered
                                         values scattered to CSR slots in LDS, lane-per-row sums (large E) */
     CANOPY_KERNEL_FILTER_REFINE = 5, /* cut_off > 0, no per-row output: a fast unordered pass flags the rows
-                                       that might survive, an exact CSR-order pass recomputes only those.
-                                       Reported values are exactly those of the other variants. */
+                                       that might survive (up to 260 096 events: integer sums of an 8- or 4-bit table in LDS over
+                                       a stream of length-sorted rows, 12 .. 18 bits per entry), an exact CSR-order pass recomputes
+                                       only those. Reported values are exactly those of the other variants. */
     CANOPY_KERNEL_FIXED_SUM = 6,    /* no per-row output, rows of <= 63 entries: every row summed in 2^-47 fixed point
                                        (integer adds commute, so all waves share a slab: no ordering constraint),
                                        exp / log1p taken from that sum (|error| <= L*2^-48 + L*|s|*2^-53, inside the
