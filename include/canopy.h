@@ -215,7 +215,7 @@ CANOPY_API canopy_status canopy_model_set_log_probabilities(canopy_ctx* ctx, can
  * reads, which a model with a row stream otherwise leaves to the first pass that needs them); a no-op for the row kernels.
  * One-off per model, independent of p.
  * kernel = CANOPY_KERNEL_AUTO prepares what AUTO will pick. canopy_quantify_async prepares lazily
- * (and synchronously) when this was not called; a pass that is being CAPTURED cannot: prepare its variant first. Returns CANOPY_ERR_UNSUPPORTED if the variant was
+ * (and synchronously) when this was not called (canopy_graph_capture runs one ordinary pass before it captures, for that reason). Returns CANOPY_ERR_UNSUPPORTED if the variant was
  * asked for explicitly and the model cannot be represented in it (E >= 2^19 or absurd row lengths).
  */
 CANOPY_API canopy_status canopy_model_prepare(canopy_ctx* ctx, canopy_model* model, int32_t kernel);
